@@ -1,0 +1,339 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/make_golden.py
+
+The fixtures are pure data (inputs, weights, expected outputs/gradients, recorded random draws).
+No reference source text is written anywhere.  The committed fixtures are what pins
+`oracle/mmae_oracle.py` (and, through it, the HIP path) to the reference; see DESIGN.md "Oracle".
+
+Everything is generated with fixed torch seeds on CPU, float32 (torch 2.10.0 CPU in this image).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_loader  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+class Bag(dict):
+    def put(self, prefix, **kw):
+        for k, v in kw.items():
+            self[prefix + "/" + k] = npy(v)
+
+
+def grads_of(out, g, tensors):
+    gs = torch.autograd.grad(out, tensors, g, allow_unused=True)
+    return [torch.zeros_like(t) if x is None else x for x, t in zip(gs, tensors)]
+
+
+def state(mod, prefix=""):
+    return {prefix + k: v for k, v in mod.state_dict().items()}
+
+
+def rand_init_(mod, gen, scale=0.2):
+    """Perturb all params (LN gammas away from 1, biases away from 0) so that fixtures pin every term."""
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if not p.requires_grad:
+                continue
+            p.add_(scale * torch.randn(p.shape, generator=gen) * (p.abs().mean() + 0.1))
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_ops(ref):
+    bag = Bag()
+    gen = torch.Generator().manual_seed(1234)
+    R = lambda *s: torch.randn(*s, generator=gen)
+
+    # a2: sincos pos-emb (multimae_utils.py:29-45) incl. a non-square grid (pins the meshgrid quirk)
+    bag.put("sincos_4x4_32", out=ref.mu.build_2d_sincos_posemb(4, 4, 32))
+    bag.put("sincos_2x3_16", out=ref.mu.build_2d_sincos_posemb(2, 3, 16))
+
+    # a7: bias-less LayerNorm (zorro_utils.py:103-110)
+    ln = ref.zu.LayerNorm(32); rand_init_(ln, gen)
+    x = R(3, 5, 32).requires_grad_(); g = R(3, 5, 32)
+    y = ln(x)
+    gx, gg = grads_of(y, g, [x, ln.gamma])
+    bag.put("layernorm", x=x, gamma=ln.gamma, y=y, g=g, gx=gx, ggamma=gg)
+
+    # a8: Attention, self / zorro-masked (zorro_utils.py:170-194)
+    attn = ref.zu.Attention(dim=32, dim_head=32, heads=2); rand_init_(attn, gen)
+    types = torch.tensor([0, 0, 0, 1, 1, 2, 2, 3, 3, 3])
+    zmask = (types[:, None] == types[None, :]) | (types[:, None] == 3)
+    x = R(2, 10, 32).requires_grad_(); g = R(2, 10, 32)
+    y = attn(x, attn_mask=zmask)
+    ps = [x] + list(attn.parameters())
+    gs = grads_of(y, g, ps)
+    bag.put("attn_self", x=x, mask=zmask, y=y, g=g, gx=gs[0], types=types,
+            **{"w." + k: v for k, v in attn.state_dict().items()},
+            **{"gw." + n: gi for (n, _), gi in zip(attn.named_parameters(), gs[1:])})
+    # unmasked
+    y = attn(x)
+    gs = grads_of(y, g, ps)
+    bag.put("attn_self_nomask", y=y, gx=gs[0])
+
+    # a13: cross attention with pool mask, one return type has no tokens (fully masked row -> uniform)
+    ctx_types = torch.tensor([0, 0, 0, 0, 2, 2, 3, 3, 3, 3])  # no type-1 token
+    rtypes = torch.tensor([0, 1, 2, 3])
+    pmask = (rtypes[:, None] == ctx_types[None, :]) | (rtypes[:, None] == 3)
+    q = R(2, 4, 32).requires_grad_(); ctx = R(2, 10, 32).requires_grad_(); g = R(2, 4, 32)
+    y = attn(q, context=ctx, attn_mask=pmask)
+    gs = grads_of(y, g, [q, ctx] + list(attn.parameters()))
+    bag.put("attn_pool", q=q, ctx=ctx, mask=pmask, ctx_types=ctx_types, y=y, g=g, gq=gs[0], gctx=gs[1],
+            **{"gw." + n: gi for (n, _), gi in zip(attn.named_parameters(), gs[2:])})
+    # a15: cross attention, no mask, 1 query; and with an EMPTY context (dropped modality)
+    q1 = R(2, 1, 32).requires_grad_(); g1 = R(2, 1, 32)
+    ctx3 = R(2, 3, 32).requires_grad_()
+    y = attn(q1, context=ctx3)
+    gs = grads_of(y, g1, [q1, ctx3])
+    bag.put("attn_cross1", q=q1, ctx=ctx3, y=y, g=g1, gq=gs[0], gctx=gs[1])
+    y = attn(q1, context=torch.zeros(2, 0, 32))
+    bag.put("attn_cross_empty", y=y)
+
+    # a9: GEGLU feed-forward (zorro_utils.py:115-128); inner = int(32*4*2/3) = 85 (odd on purpose)
+    ff = ref.zu.FeedForward(dim=32, mult=4); rand_init_(ff, gen)
+    x = R(2, 7, 32).requires_grad_(); g = R(2, 7, 32)
+    y = ff(x)
+    gs = grads_of(y, g, [x] + list(ff.parameters()))
+    bag.put("feedforward", x=x, y=y, g=g, gx=gs[0],
+            **{"w." + k: v for k, v in ff.state_dict().items()},
+            **{"gw." + n: gi for (n, _), gi in zip(ff.named_parameters(), gs[1:])})
+
+    # Mlp (zorro_utils.py:131-148)
+    mlp = ref.zu.Mlp(in_features=32, hidden_features=128); rand_init_(mlp, gen)
+    x = R(2, 4, 32).requires_grad_(); g = R(2, 4, 32)
+    y = mlp(x)
+    gs = grads_of(y, g, [x] + list(mlp.parameters()))
+    bag.put("mlp", x=x, y=y, g=g, gx=gs[0],
+            **{"w." + k: v for k, v in mlp.state_dict().items()},
+            **{"gw." + n: gi for (n, _), gi in zip(mlp.named_parameters(), gs[1:])})
+
+    # a10: Block (zorro_utils.py:227-240)
+    blk = ref.zu.Block(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=ref.zu.LayerNorm); rand_init_(blk, gen)
+    x = R(2, 10, 32).requires_grad_(); g = R(2, 10, 32)
+    y = blk(x, zmask)
+    gs = grads_of(y, g, [x] + list(blk.parameters()))
+    bag.put("block", x=x, mask=zmask, types=types, y=y, g=g, gx=gs[0],
+            **{"w." + k: v for k, v in blk.state_dict().items()},
+            **{"gw." + n: gi for (n, _), gi in zip(blk.named_parameters(), gs[1:])})
+
+    # a12: Block_Fusion, canonical downstream copy (DSI-MM/zorro_utils.py:243-258)
+    fus = ref.zu.Block_Fusion(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=ref.zu.LayerNorm); rand_init_(fus, gen)
+    x = R(2, 6, 4, 32).requires_grad_(); g = R(2, 6, 32)
+    y = fus(x, None)
+    gs = grads_of(y, g, [x] + list(fus.parameters()))
+    bag.put("block_fusion", x=x, y=y, g=g, gx=gs[0],
+            **{"w." + k: v for k, v in fus.state_dict().items()},
+            **{"gw." + n: gi for (n, _), gi in zip(fus.named_parameters(), gs[1:])})
+
+    # a1: PatchedInputAdapter (input_adapters.py:97-119), C=3, patch 8, 32x32 -> 16 patches, D=32
+    pia = ref.ia.PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32)
+    rand_init_(pia, gen)
+    x = R(2, 3, 32, 32); g = R(2, 16, 32)
+    y = pia(x)
+    gs = grads_of(y, g, [pia.proj.weight, pia.proj.bias])
+    bag.put("patched_input", x=x, y=y, g=g, gweight=gs[0], gbias=gs[1],
+            **{"w." + k: v for k, v in pia.state_dict().items()})
+    # a3: FusionInputAdapter (input_adapters.py:185-206)
+    fia = ref.ia.FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32)
+    x = R(2, 16, 32)
+    bag.put("fusion_input", x=x, y=fia(x), **{"w." + k: v for k, v in fia.state_dict().items()})
+
+    # a14: SpatialOutputAdapter (output_adapters_simple.py:146-188), 2 decoder blocks @64, 2 heads (dh 32)
+    soa = ref.oa.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens_enc=32,
+                                      dim_tokens=64, depth=2, num_heads=2, image_size=32, task="s2",
+                                      context_tasks=["s1", "s2", "dem"])
+    rand_init_(soa, gen)
+    enc = R(2, 16, 32).requires_grad_(); g = R(2, 3, 32, 32)
+    info = {"image_size": (32, 32)}
+    y = soa(enc, info, None, None)
+    names = [n for n, p in soa.named_parameters() if p.requires_grad]
+    params = [p for n, p in soa.named_parameters() if p.requires_grad]
+    gs = grads_of(y, g, [enc] + params)
+    bag.put("spatial_output", enc=enc, y=y, g=g, genc=gs[0],
+            **{"w." + k: v for k, v in soa.state_dict().items()},
+            **{"gw." + n: gi for n, gi in zip(names, gs[1:])})
+
+    # a16: masked losses (criterion.py:85-115, 142-172)
+    pred = R(3, 3, 32, 32).requires_grad_(); tgt = R(3, 3, 32, 32)
+    mask = (torch.rand(3, 16, generator=gen) > 0.5).long()
+    mask[2] = 0  # a sample with nothing masked -> 0/0 -> nan -> dropped by nanmean
+    for name, cls in (("mse", ref.cr.MaskedMSELoss), ("l1", ref.cr.MaskedL1Loss)):
+        fn = cls(patch_size=8, stride=1)
+        l = fn(pred, tgt, mask=mask)
+        (gp,) = grads_of(l, torch.tensor(1.0), [pred])
+        bag.put("masked_" + name, pred=pred, tgt=tgt, mask=mask, loss=l, gpred=gp)
+        l = fn(pred, tgt, mask=None)
+        (gp,) = grads_of(l, torch.tensor(1.0), [pred])
+        bag.put("masked_" + name + "_nomask", loss=l, gpred=gp)
+        l0 = fn(pred, tgt, mask=torch.zeros(3, 16, dtype=torch.long))
+        bag.put("masked_" + name + "_zeromask", loss=l0)  # integer tensor(0), criterion.py:101-102
+        fnp = cls(patch_size=8, stride=1, norm_pix=True)
+        l = fnp(pred, tgt, mask=mask)
+        (gp,) = grads_of(l, torch.tensor(1.0), [pred])
+        bag.put("masked_" + name + "_normpix", loss=l, gpred=gp)
+
+    # a17: dino_loss_func (criterion.py:328-335)
+    s = R(4, 32).requires_grad_(); t = R(4, 32).requires_grad_()
+    l = ref.cr.dino_loss_func(s, t)
+    gs_, gt_ = grads_of(l, torch.tensor(1.0), [s, t])
+    bag.put("dino", student=s, teacher=t, loss=l, gstudent=gs_, gteacher=gt_)
+
+    # a18: HardNegtive_loss (criterion.py:233-268); `.cuda()` at :242 made a no-op for the CPU run only
+    hn = ref.cr.HardNegtive_loss()
+    o1 = R(4, 32).requires_grad_(); o2 = R(4, 32).requires_grad_()
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        l = hn(o1, o2)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    g1, g2 = grads_of(l, torch.tensor(1.0), [o1, o2])
+    bag.put("hardneg", out_1=o1, out_2=o2, loss=l, g1=g1, g2=g2)
+
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **bag)
+    print("ops.npz:", len(bag), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------
+E2E_CFG = dict(dim_tokens=32, depth=2, dim_head=32, heads=2, image_size=64, patch_size=16,
+               decoder_dim=32, decoder_depth=1, decoder_heads=1)
+CHANNELS = (("s1", 1), ("s2", 3), ("dem", 1))
+
+
+def harness_losses(ref, out, x, masks):
+    """Transcription of the loss block of train_one_epoch (pretraining/pretrain_mmae.py:479-500),
+    with NoWeightingStrategy (identity, utils/task_balancing.py:11-19)."""
+    preds, _, pooled, ori, fus, s1_t, s2_t, dem_t = out
+    fns = {"s1": ref.cr.MaskedMSELoss(patch_size=16, stride=1),
+           "s2": ref.cr.MaskedMSELoss(patch_size=16, stride=1),
+           "dem": ref.cr.MaskedL1Loss(patch_size=16, stride=1)}
+    task_losses = {t: fns[t](preds[t].float(), x[t], mask=masks.get(t, None)) for t in preds}
+    s1_f, s2_f, dsm_f, fus_f = [c.squeeze() for c in torch.chunk(pooled, 4, dim=1)]
+    s1_t, s2_t, dem_t = s1_t.squeeze(), s2_t.squeeze(), dem_t.squeeze()
+    d = ref.cr.dino_loss_func
+    loss_contra = d(s1_t, s1_f) + d(s2_t, s2_f) + d(dem_t, dsm_f)
+    loss = sum(task_losses.values()) + 0.3 * loss_contra
+    return task_losses, loss_contra, loss
+
+
+def gen_e2e(ref):
+    torch.manual_seed(7)
+    model = ref_loader.build_reference_model(ref, channels=CHANNELS, **E2E_CFG)
+    gen = torch.Generator().manual_seed(99)
+    rand_init_(model, gen, scale=0.3)
+    with torch.no_grad():
+        model.mask_embedding.add_(0.05 * torch.randn(model.mask_embedding.shape, generator=gen))
+    model.train()
+    B, P = 2, 16
+    x = {d: torch.randn(B, c, 64, 64, generator=gen) for d, c in CHANNELS}
+    bag = Bag()
+    bag["config"] = np.array(json.dumps(dict(E2E_CFG, channels=CHANNELS, B=B)))
+    for k, v in model.state_dict().items():
+        bag["state/" + k] = npy(v)
+    for d in x:
+        bag["x/" + d] = npy(x[d])
+
+    def mask_case(keep):
+        m = {}
+        for d, idx in keep.items():
+            row = torch.ones(P, dtype=torch.long)
+            row[torch.tensor(idx, dtype=torch.long)] = 0
+            m[d] = row[None].repeat(B, 1)
+        return m
+
+    cases = {
+        # uneven split, 24 of 48 kept
+        "split": mask_case({"s1": [0, 3, 5, 6, 9, 10, 12, 15, 2, 7], "s2": [1, 2, 4, 8, 11, 13, 14, 0], "dem": [5, 6, 7, 9, 12, 3]}),
+        # dem fully dropped (N_m = 0): fully-masked pool row + empty contrastive context
+        "dropdem": mask_case({"s1": list(range(0, 16, 2)) + [1, 3], "s2": list(range(1, 16, 2)) + [0, 2, 4, 6], "dem": []}),
+        # one modality only
+        "onlys2": mask_case({"s1": [], "s2": list(range(16)), "dem": []}),
+    }
+    names = [n for n, p in model.named_parameters()]
+    for cname, masks in cases.items():
+        N = int(sum((m[0] == 0).sum() for m in masks.values()))
+        captured = {}
+        def hook_blk(mod, args):
+            captured["zorro"] = args[1].clone()
+
+        def hook_pool(mod, args, kwargs):
+            if kwargs.get("attn_mask") is not None and "pool" not in captured:
+                captured["pool"] = kwargs["attn_mask"].clone()
+
+        h1 = model.blocks[0].register_forward_pre_hook(hook_blk)
+        h2 = model.attn_pool.register_forward_pre_hook(hook_pool, with_kwargs=True)
+        model.zero_grad()
+        out = model(x, task_masks=masks, num_encoded_tokens=N)
+        h1.remove(); h2.remove()
+        task_losses, loss_contra, loss = harness_losses(ref, out, x, masks)
+        loss.backward()
+        preds, tm, pooled, ori, fus, s1_t, s2_t, dem_t = out
+        pre = "case_%s/" % cname
+        bag[pre + "N"] = np.array(N)
+        for d in masks:
+            bag[pre + "mask/" + d] = npy(masks[d])
+            bag[pre + "pred/" + d] = npy(preds[d])
+            bag[pre + "task_loss/" + d] = npy(task_losses[d])
+        bag.put(pre[:-1], pooled=pooled, ori_tokens=ori, fusion_tokens=fus, ret_s1=s1_t, ret_s2=s2_t, ret_dem=dem_t,
+                loss_contra=loss_contra, loss=loss, zorro_mask=captured["zorro"], pool_mask=captured["pool"])
+        if cname != "onlys2":
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    bag[pre + "grad/" + n] = npy(p.grad)
+    bag["param_names"] = np.array(json.dumps(names))
+    np.savez_compressed(os.path.join(OUT, "e2e_tiny.npz"), **bag)
+    print("e2e_tiny.npz:", len(bag), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_masks(ref):
+    """a4: generate_random_masks (multimae_crossattn.py:205-278) with the global-RNG draws recorded by
+    replaying the same seed: Dirichlet(alphas).sample((1,)), M x rand(1,P), rand_like(mask_all)."""
+    from torch.distributions.dirichlet import Dirichlet
+    bag = Bag()
+    model = ref_loader.build_reference_model(ref, channels=CHANNELS, **E2E_CFG)
+    cases = []
+    for seed, (P, N, B) in enumerate([(16, 24, 2), (16, 24, 2), (16, 8, 1), (16, 40, 2), (64, 96, 3),
+                                      (256, 384, 2), (256, 384, 2), (256, 128, 1), (256, 700, 1), (16, 48, 2)]):
+        toks = {d: torch.zeros(B, P, 4) for d, _ in CHANNELS}
+        torch.manual_seed(1000 + seed)
+        tm, ids_keep, ids_restore = model.generate_random_masks(toks, N, alphas=1.0)
+        torch.manual_seed(1000 + seed)
+        dirichlet = Dirichlet(torch.Tensor([1.0] * 3)).sample((1,))
+        noises = [torch.rand(1, P) for _ in range(3)]
+        noise_all = torch.rand(1, 3 * P)
+        pre = "mask%d" % seed
+        bag.put(pre, P=np.array(P), N=np.array(N), B=np.array(B), dirichlet=dirichlet, noise=torch.cat(noises, 0),
+                noise_all=noise_all, ids_keep=ids_keep, ids_restore=ids_restore,
+                **{"task_mask." + d: tm[d] for d in tm})
+        cases.append(pre)
+    bag["cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **bag)
+    print("masks.npz:", len(bag), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    ref = ref_loader.load()
+    gen_ops(ref)
+    gen_e2e(ref)
+    gen_masks(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE ONLY -- loader for the *actual* reference implementation.
+
+Only usable in the build container, where the read-only reference checkout lives at
+/root/reference.  It is used by `oracle/make_golden.py` to generate the committed fixtures in
+`tests/golden/` and by `tests/test_oracle_vs_reference.py` (skipped when the checkout is absent,
+e.g. on the GPU box).  Nothing in the product package imports this file.
+
+Why a custom loader:
+  * pretraining/multimae/__init__.py imports .multimae -> .zorro_utils, and
+    pretraining/multimae/zorro_utils.py:255 has a U+FF1A character (SyntaxError), so the package
+    cannot be imported as committed.
+  * downstream/instance_segmentation/modeling/multimae/zorro_utils.py is the same file with the
+    working Block_Fusion (lines 249, 255) -- it is what the checkpoints are loaded with.
+We therefore register an empty `multimae` package object whose __path__ points at the reference
+directory (skipping its __init__), bind the downstream zorro_utils as `multimae.zorro_utils`, and
+import the remaining reference modules unmodified.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("MMAE_REFERENCE_ROOT", "/root/reference")
+MM = os.path.join(REF_ROOT, "pretraining", "multimae")
+DSI_MM = os.path.join(REF_ROOT, "downstream", "instance_segmentation", "modeling", "multimae")
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(MM, "multimae_crossattn.py")) and os.path.isfile(
+        os.path.join(DSI_MM, "zorro_utils.py"))
+
+
+_cache = None
+
+
+def load():
+    """Returns a namespace with the reference modules: zu, mc, ia, oa, cr, mu."""
+    global _cache
+    if _cache is not None:
+        return _cache
+    if not available():
+        raise RuntimeError("reference checkout not present at %s" % REF_ROOT)
+    saved = {k: v for k, v in sys.modules.items() if k == "multimae" or k.startswith("multimae.")}
+    for k in saved:
+        del sys.modules[k]
+    pkg = types.ModuleType("multimae")
+    pkg.__path__ = [MM]
+    sys.modules["multimae"] = pkg
+    spec = importlib.util.spec_from_file_location("multimae.zorro_utils", os.path.join(DSI_MM, "zorro_utils.py"))
+    zu = importlib.util.module_from_spec(spec)
+    sys.modules["multimae.zorro_utils"] = zu
+    spec.loader.exec_module(zu)
+    ns = types.SimpleNamespace(
+        zu=zu,
+        mu=importlib.import_module("multimae.multimae_utils"),
+        cr=importlib.import_module("multimae.criterion"),
+        ia=importlib.import_module("multimae.input_adapters"),
+        oa=importlib.import_module("multimae.output_adapters_simple"),
+        mc=importlib.import_module("multimae.multimae_crossattn"),
+    )
+    # Leave no `multimae.*` entries behind: the product package has a sub-package of the same name
+    # (incomplete_multimodal_fusion_amd.multimae) and tests must never pick up the reference by accident.
+    for k in [k for k in sys.modules if k == "multimae" or k.startswith("multimae.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+    _cache = ns
+    return ns
+
+
+def build_reference_model(ref, *, dim_tokens, depth, dim_head, heads, image_size, patch_size=16,
+                          channels=(("s1", 1), ("s2", 3), ("dem", 1)),
+                          decoder_dim=256, decoder_depth=2, decoder_heads=8):
+    """Builds reference adapters + MultiMAE the way pretraining/pretrain_mmae.py:193-246 does,
+    with free sizes (the class takes arbitrary dims; the factories only fix presets)."""
+    from functools import partial
+    T = ref.zu.TokenTypes
+    in_domains = [c[0] for c in channels]
+    input_adapters = {
+        d: ref.ia.PatchedInputAdapter(num_channels=c, stride_level=1, patch_size_full=patch_size,
+                                      image_size=image_size)
+        for d, c in channels
+    }
+    output_adapters = {
+        d: ref.oa.SpatialOutputAdapter(num_channels=c, stride_level=1, patch_size_full=patch_size,
+                                       dim_tokens=decoder_dim, depth=decoder_depth,
+                                       num_heads=decoder_heads, use_task_queries=True, task=d,
+                                       context_tasks=list(in_domains), use_xattn=True)
+        for d, c in channels
+    }
+    input_adapters["fusion"] = ref.ia.FusionInputAdapter(num_channels=1, stride_level=1,
+                                                         patch_size_full=patch_size,
+                                                         image_size=image_size)
+    num_patches = (image_size // patch_size) ** 2
+    model = ref.mc.MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters,
+                            num_global_tokens=1, dim_tokens=dim_tokens, depth=depth,
+                            dim_head=dim_head, heads=heads, ff_mult=4,
+                            num_fusion_tokens=num_patches,
+                            return_token_types=(T.S1, T.S2, T.DEM, T.FUSION),
+                            drop_path_rate=0.0, norm_layer=ref.zu.LayerNorm)
+    return model
