@@ -1,0 +1,132 @@
+/* mmae_hip.h -- C ABI of libmmae_hip.so: the MI355X (gfx950) kernels behind the MultiMAE fusion-token hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI on this path: every entry point below replaces a
+ * *composition of stock ATen ops* inside the reference's Python modules; the citation on each function names the
+ * reference lines it stands in for (paths relative to the reference checkout; DSI-MM = downstream/
+ * instance_segmentation/modeling/multimae, MM = pretraining/multimae, PT = pretraining).  The only consumer is
+ * incomplete_multimodal_fusion_amd/_lib.py (ctypes), which wraps them in torch.autograd.Functions inside module
+ * classes that keep the reference's constructor / forward signatures and state-dict names.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, strides in ELEMENTS; no torch types.  `stream` is a hipStream_t.
+ *   - dtype: MMAE_F32 (0) or MMAE_BF16 (1).  fp32 accumulation everywhere.
+ *   - pointers of vectorised operands must be 16-byte aligned, strides multiples of 8 (attention) or 4 (row ops).
+ *   - every function returns 0 on success, MMAE_ERR_ARG (-1) for invalid arguments (nothing is launched),
+ *     MMAE_ERR_LAUNCH (-2) when the HIP launch failed.  Asynchronous: no host synchronisation, no allocation.
+ */
+#ifndef MMAE_HIP_H
+#define MMAE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMAE_F32 0
+#define MMAE_BF16 1
+#define MMAE_ABI_VERSION 1
+int mmae_abi_version(void);
+
+/* ---- masked multi-head attention (DSI-MM/zorro_utils.py:181-193; decoder core MM/multimae_utils.py:172-179) ----------
+ * Segment ("Zorro") mask as data: sample b has nseg query segments and nseg key segments (arrays (B, nseg), global row
+ * index + length).  A query in segment s < nseg-1 attends key segment s; a query in the LAST segment attends every key
+ * of its sample (fusion rule, MM/multimae_crossattn.py:441-447; pool rule :489-493).  Empty key segment:
+ * empty_mode 0 -> uniform over all keys (finite masked_fill, zorro_utils.py:187), 1 -> zeros (empty context, :530-543).
+ * q/k/v/out element (row, head h, d) lives at ptr[row*stride + h*head_dim + d]; head_dim in {32, 64}.
+ * lse: (H, q_rows_total) fp32, natural log of the softmax denominator (scaled scores).  max_q_rows / max_k_rows: upper
+ * bound of the per-sample total rows (sizes the grid). */
+int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v, void* out,
+                 float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
+                 const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
+                 int max_q_rows, float scale, int empty_mode, void* stream);
+/* backward of the above (autograd of the same lines).  delta_ws: (H, q_rows_total) fp32 scratch. */
+int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                 const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                 long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,
+                 long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
+                 const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
+                 int empty_mode, void* stream);
+
+/* ---- modality attention of Block_Fusion (DSI-MM/zorro_utils.py:252-256 on MM/multimae_crossattn.py:454-462) ---------
+ * For each of the B*P (sample, patch) rows: the fusion query (row of q) attends `ns` = M+1 key/value rows of kv
+ * (kv[row] = [K (inner) | V (inner)]) named by slot_row (B*P, ns).  Rows < shared_base are token rows, each used by
+ * exactly one slot; a masked slot of patch p uses the shared mask-embedding row shared_base + p. */
+int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
+                     const void* kv, long kv_stride, const int* slot_row, void* out, long out_stride, float scale,
+                     void* stream);
+int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
+                     const void* kv, long kv_stride, const int* slot_row, const void* dout, long do_stride, void* dq,
+                     long dq_stride, void* dkv, long dkv_stride, int shared_base, float scale, void* stream);
+
+/* ---- fused residual add + LayerNorm / double LayerNorm (DSI-MM/zorro_utils.py:103-110, :176, :124, :238-239, :255-257;
+ *      decoder nn.LayerNorm eps 1e-6, MM/output_adapters_simple.py:75; final norm MM/multimae_crossattn.py:472) ------
+ * x_new = x + delta (fp32 residual stream; delta optional, dtype_delta);  y = LN2(LN1(x_new)) (gamma2 == NULL: single
+ * LN), betas optional.  stats: (rows, 4) = mean1, rstd1, mean2, rstd2.  D multiple of 4, <= 1024. */
+int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, const float* x, const void* delta, float* x_new,
+                    void* y, const float* gamma1, const float* beta1, float eps1, const float* gamma2,
+                    const float* beta2, float eps2, float* stats, void* stream);
+/* gx = LN-backward(gy) + gx_up (optional); written as fp32 (gx) and/or dtype_delta (gdelta).  Column sums
+ * dgamma1/2, dbeta1/2 (fp32, D) via workspace ws of mmae_add_ln_bwd_ws_floats(rows, D) floats. */
+int mmae_add_ln_bwd_ws_floats(long rows, int D);
+int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy,
+                    const float* gx_up, const float* gamma1, const float* beta1, const float* gamma2,
+                    const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1, float* dgamma2,
+                    float* dbeta2, float* ws, void* stream);
+
+/* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j], exact erf GELU ---------------- */
+int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream);
+int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream);
+/* ---- GELU of Mlp (DSI-MM/zorro_utils.py:141-143, MM/multimae_utils.py:148-150) -------------------------------------- */
+int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* stream);
+int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, void* dx, void* stream);
+
+/* ---- row gather / scatter (token selection MM/multimae_crossattn.py:402-407, :531-541; pos-emb lookup) ------------- */
+int mmae_gather_rows(int dtype, long rows, int W, const void* src, long src_stride, const int* idx, void* out,
+                     long out_stride, void* stream);
+/* dst[idx[r]] (+)= src[r] for rows with idx[r] >= 0 and (filter == NULL or filter[r] == filter_value); plain
+ * read-modify-write: destination rows must be unique within one call (call once per modality when they are not). */
+int mmae_scatter_rows(int dtype, long rows, int W, const void* src, long src_stride, const int* idx, void* dst,
+                      long dst_stride, int accumulate, const int* filter, int filter_value, void* stream);
+
+/* ---- patchify of KEPT patches (MM/input_adapters.py:104-110 + MM/multimae_crossattn.py:402-407) ---------------------
+ * out (B*tokens_per_sample, Kcat): row r of sample r / tokens_per_sample, modality tok_mod[r], patch tok_patch[r]:
+ * pixels in (c ph pw) order at columns [col_offsets[m], +C_m*patch^2), zeros elsewhere, optional one-hot(modality) at
+ * onehot_offset (bias column of the concatenated conv weight).  tok_mod == tok_patch == NULL: dense, one modality. */
+int mmae_patchify_gather(int dtype_out, int nmod, const float* const* images, const int* channels,
+                         const int* col_offsets, int onehot_offset, int Kcat, int B, int H, int W, int patch,
+                         const int* tok_mod, const int* tok_patch, int tokens_per_sample, void* out, void* stream);
+/* ---- unpatchify (MM/output_adapters_simple.py:183-186) -------------------------------------------------------------- */
+int mmae_unpatchify(int dtype_in, int B, int C, int H, int W, int patch, const void* tokens, float* image, void* stream);
+
+/* ---- masked reconstruction loss (MM/criterion.py:98-111 MSE kind 0, :155-168 L1 kind 1) -----------------------------
+ * pred: image (B,C,H,W) fp32 (pred_is_tokens 0) or decoder tokens (B*P, C*patch^2) of pred_dtype (fused unpatchify).
+ * mask (B, P) int64 {0,1} or NULL (= all ones).  stats[0] = loss, stats[1] = number of samples with a non-empty mask;
+ * partial_ws (B*P) and den (B) fp32 are kept for the backward.  Nothing masked -> loss 0 (criterion.py:101-102). */
+int mmae_masked_loss_fwd(int pred_dtype, int pred_is_tokens, int kind, int B, int C, int H, int W, int patch,
+                         const void* pred, const float* target, const long long* mask, float* partial_ws, float* den,
+                         float* stats, void* stream);
+int mmae_masked_loss_bwd(int pred_dtype, int pred_is_tokens, int kind, int B, int C, int H, int W, int patch,
+                         const void* pred, const float* target, const long long* mask, const float* den,
+                         const float* stats, const float* gloss, void* gpred, void* stream);
+
+/* ---- contrastive heads: dino_loss_func (MM/criterion.py:328-335), HardNegtive_loss (MM/criterion.py:233-268) -------- */
+int mmae_dino_loss_fwd(int B, int D, const float* student, const float* teacher, float student_temp,
+                       float teacher_temp, float* row_loss_ws, float* loss, void* stream);
+int mmae_dino_loss_bwd(int B, int D, const float* student, const float* teacher, float student_temp,
+                       float teacher_temp, const float* gloss, float* gstudent, void* stream);
+long mmae_hardneg_ws_floats(int B, int D);
+int mmae_hardneg_loss_fwd(int B, int D, const float* out_1, const float* out_2, float tau_plus, float beta,
+                          float temperature, float* ws, float* loss, void* stream);
+int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const float* out_2, float tau_plus, float beta,
+                          float temperature, float* ws, const float* gloss, float* g1, float* g2, void* stream);
+
+/* ---- mask bookkeeping (MM/multimae_crossattn.py:233-272 with injected draws; :402-447, :454-462, :489-493) ---------- */
+int mmae_masks_from_draws(int R, int M, int P, int N, const float* dirichlet, const float* noise,
+                          const float* noise_all, long long* mask_all, long long* ids_keep, long long* ids_restore,
+                          void* stream);
+/* int32 descriptor buffer; section offsets (15 entries, last = total ints) by mmae_descriptor_layout. */
+long mmae_descriptor_layout(int B, int M, int P, int N, long* offsets15);
+int mmae_build_descriptors(int B, int R, int M, int P, int N, const long long* mask_all, int* desc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

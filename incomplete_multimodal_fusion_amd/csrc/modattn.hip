@@ -1,0 +1,265 @@
+// Modality attention of Block_Fusion (gfx950): for every (sample, patch) the fusion token attends the M modality
+// slots of that patch plus itself -- sequence length M+1 <= 8.
+//
+// Reference: multimae_crossattn.py:454-462 builds all_tokens (B,P,M+1,D) by cloning mask_embedding and scattering
+// the kept tokens, then Block_Fusion.forward (downstream/.../zorro_utils.py:252-258) runs full attention over the
+// M+1 slots and keeps only the fusion slot (:256).  Rows are independent, so only the fusion slot's query is needed and
+// K/V of a masked slot depend on the patch only (they come from mask_embedding[p]).  Here K/V live in ONE matrix
+// kv[(token rows | P mask-embedding rows), 2*I] and `slot_row[(b,p), s]` names the row each slot reads; the
+// (B,P,M+1,D) tensor is never materialised.  HBM-bound: one wave per (b,p), 16 B per lane, heads = groups of DH/8 lanes.
+//
+// Backward: one block per patch p, its 4 waves stride over the samples; token rows are written once each (every token
+// row belongs to exactly one slot), the shared mask-embedding row `shared_base + p` is accumulated in registers over the
+// samples and stored once -> deterministic, no atomics.
+#include "common.hpp"
+#include "mmae_hip.h"
+
+#define MA_MAXS 8
+
+template <typename T> __device__ __forceinline__ void ld8f(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8f<float>(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+}
+template <> __device__ __forceinline__ void ld8f<bf16>(const bf16* p, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+template <typename T> __device__ __forceinline__ void st8f(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8f<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void st8f<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+template <int DH> __device__ __forceinline__ float head_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < DH / 8; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct ModAttn {
+    const void* q; const void* kv; const int* slot_row; void* out;
+    const void* dout; void* dq; void* dkv;
+    long q_stride, kv_stride, out_stride, do_stride, dq_stride, dkv_stride;
+    long rows;            // B*P
+    int I, ns, P, B, shared_base;
+    float scale;
+};
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void modattn_fwd_kernel(ModAttn p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;                 // wave-uniform
+    const T* q = reinterpret_cast<const T*>(p.q) + row * p.q_stride;
+    const T* kv = reinterpret_cast<const T*>(p.kv);
+    T* out = reinterpret_cast<T*>(p.out) + row * p.out_stride;
+    int srow[MA_MAXS];
+#pragma unroll
+    for (int s = 0; s < MA_MAXS; ++s) srow[s] = s < p.ns ? p.slot_row[row * p.ns + s] : 0;
+    for (int c0 = 0; c0 < p.I; c0 += 512) {
+        const int col = c0 + 8 * lane;
+        const bool act = col < p.I;
+        float q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q8[j] = 0.f;
+        if (act) ld8f<T>(q + col, q8);
+        float sc[MA_MAXS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < MA_MAXS; ++s) {
+            sc[s] = -INFINITY;
+            if (s < p.ns) {
+                float k8[8], d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) k8[j] = 0.f;
+                if (act) ld8f<T>(kv + (long)srow[s] * p.kv_stride + col, k8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += q8[j] * k8[j];
+                sc[s] = head_sum<DH>(d) * p.scale;
+                mx = fmaxf(mx, sc[s]);
+            }
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int s = 0; s < MA_MAXS; ++s) { sc[s] = s < p.ns ? __expf(sc[s] - mx) : 0.f; den += sc[s]; }
+        const float inv = 1.f / den;
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < MA_MAXS; ++s) {
+            if (s < p.ns && act) {
+                float v8[8];
+                ld8f<T>(kv + (long)srow[s] * p.kv_stride + p.I + col, v8);
+                const float w = sc[s] * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] += w * v8[j];
+            }
+        }
+        if (act) st8f<T>(out + col, o8);
+    }
+}
+
+// NCH = ceil(I / 512) register chunks of shared-row accumulators
+template <typename T, int DH, int NCH>
+__global__ __launch_bounds__(256) void modattn_bwd_kernel(ModAttn p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2*I]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pp = blockIdx.x;                                     // patch
+    const T* kv = reinterpret_cast<const T*>(p.kv);
+    T* dkv = reinterpret_cast<T*>(p.dkv);
+    float accK[NCH][8], accV[NCH][8];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { accK[ch][j] = 0.f; accV[ch][j] = 0.f; }
+
+    for (int b = wave; b < p.B; b += 4) {
+        const long row = (long)b * p.P + pp;
+        const T* q = reinterpret_cast<const T*>(p.q) + row * p.q_stride;
+        const T* dout = reinterpret_cast<const T*>(p.dout) + row * p.do_stride;
+        T* dq = reinterpret_cast<T*>(p.dq) + row * p.dq_stride;
+        int srow[MA_MAXS];
+#pragma unroll
+        for (int s = 0; s < MA_MAXS; ++s) srow[s] = s < p.ns ? p.slot_row[row * p.ns + s] : 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int col = ch * 512 + 8 * lane;
+            const bool act = col < p.I;
+            float q8[8], g8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { q8[j] = 0.f; g8[j] = 0.f; }
+            if (act) { ld8f<T>(q + col, q8); ld8f<T>(dout + col, g8); }
+            float sc[MA_MAXS], dp[MA_MAXS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < MA_MAXS; ++s) {
+                sc[s] = -INFINITY; dp[s] = 0.f;
+                if (s < p.ns) {
+                    float k8[8], v8[8], d = 0.f, e = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { k8[j] = 0.f; v8[j] = 0.f; }
+                    if (act) {
+                        ld8f<T>(kv + (long)srow[s] * p.kv_stride + col, k8);
+                        ld8f<T>(kv + (long)srow[s] * p.kv_stride + p.I + col, v8);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { d += q8[j] * k8[j]; e += g8[j] * v8[j]; }
+                    sc[s] = head_sum<DH>(d) * p.scale;
+                    dp[s] = head_sum<DH>(e);
+                    mx = fmaxf(mx, sc[s]);
+                }
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int s = 0; s < MA_MAXS; ++s) { sc[s] = s < p.ns ? __expf(sc[s] - mx) : 0.f; den += sc[s]; }
+            const float inv = 1.f / den;
+            float dot = 0.f;
+#pragma unroll
+            for (int s = 0; s < MA_MAXS; ++s) { sc[s] *= inv; dot += sc[s] * dp[s]; }
+            float dq8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dq8[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < MA_MAXS; ++s) {
+                if (s < p.ns && act) {
+                    const float ds = sc[s] * (dp[s] - dot) * p.scale;
+                    float k8[8], dk8[8], dv8[8];
+                    ld8f<T>(kv + (long)srow[s] * p.kv_stride + col, k8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { dq8[j] += ds * k8[j]; dk8[j] = ds * q8[j]; dv8[j] = sc[s] * g8[j]; }
+                    if (srow[s] < p.shared_base) {
+                        st8f<T>(dkv + (long)srow[s] * p.dkv_stride + col, dk8);
+                        st8f<T>(dkv + (long)srow[s] * p.dkv_stride + p.I + col, dv8);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { accK[ch][j] += dk8[j]; accV[ch][j] += dv8[j]; }
+                    }
+                }
+            }
+            if (act) st8f<T>(dq + col, dq8);
+        }
+    }
+    // reduce the shared (mask-embedding) row over the 4 waves and store it once
+    const int I2 = 2 * p.I;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int col = ch * 512 + 8 * lane;
+        if (col < p.I) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[wave * I2 + col + j] = accK[ch][j]; red[wave * I2 + p.I + col + j] = accV[ch][j]; }
+        }
+    }
+    __syncthreads();
+    T* drow = dkv + (long)(p.shared_base + pp) * p.dkv_stride;
+    for (int c = threadIdx.x; c < I2; c += 256)
+        drow[c] = from_f<T>(red[c] + red[I2 + c] + red[2 * I2 + c] + red[3 * I2 + c]);
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int ma_check(int dtype, int head_dim, int B, int P, int ns, int I, long a, long b, long c) {
+    if (dtype != MMAE_F32 && dtype != MMAE_BF16) return MMAE_ERR_ARG;
+    if (head_dim != 32 && head_dim != 64) return MMAE_ERR_ARG;
+    if (B <= 0 || P <= 0 || ns <= 0 || ns > MA_MAXS || I <= 0 || (I % head_dim) || I > 1024) return MMAE_ERR_ARG;
+    if ((a % 8) || (b % 8) || (c % 8)) return MMAE_ERR_ARG;
+    return MMAE_OK;
+}
+
+extern "C" int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
+                                const void* kv, long kv_stride, const int* slot_row, void* out, long out_stride,
+                                float scale, void* stream) {
+    int rc = ma_check(dtype, head_dim, B, P, ns, inner, q_stride, kv_stride, out_stride);
+    if (rc) return rc;
+    if (!q || !kv || !slot_row || !out || !al16(q) || !al16(kv) || !al16(out)) return MMAE_ERR_ARG;
+    ModAttn p{};
+    p.q = q; p.kv = kv; p.slot_row = slot_row; p.out = out; p.q_stride = q_stride; p.kv_stride = kv_stride;
+    p.out_stride = out_stride; p.rows = (long)B * P; p.I = inner; p.ns = ns; p.P = P; p.B = B; p.scale = scale;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(p.rows, 4)), blk(256);
+    if (dtype == MMAE_BF16) {
+        if (head_dim == 64) hipLaunchKernelGGL((modattn_fwd_kernel<bf16, 64>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((modattn_fwd_kernel<bf16, 32>), grid, blk, 0, st, p);
+    } else {
+        if (head_dim == 64) hipLaunchKernelGGL((modattn_fwd_kernel<float, 64>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((modattn_fwd_kernel<float, 32>), grid, blk, 0, st, p);
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
+                                const void* kv, long kv_stride, const int* slot_row, const void* dout, long do_stride,
+                                void* dq, long dq_stride, void* dkv, long dkv_stride, int shared_base, float scale,
+                                void* stream) {
+    int rc = ma_check(dtype, head_dim, B, P, ns, inner, q_stride, kv_stride, do_stride);
+    if (rc) return rc;
+    if ((dq_stride % 8) || (dkv_stride % 8) || shared_base < 0) return MMAE_ERR_ARG;
+    if (!q || !kv || !slot_row || !dout || !dq || !dkv || !al16(q) || !al16(kv) || !al16(dout) || !al16(dq) || !al16(dkv)) return MMAE_ERR_ARG;
+    ModAttn p{};
+    p.q = q; p.kv = kv; p.slot_row = slot_row; p.dout = dout; p.dq = dq; p.dkv = dkv;
+    p.q_stride = q_stride; p.kv_stride = kv_stride; p.do_stride = do_stride; p.dq_stride = dq_stride; p.dkv_stride = dkv_stride;
+    p.rows = (long)B * P; p.I = inner; p.ns = ns; p.P = P; p.B = B; p.shared_base = shared_base; p.scale = scale;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(P), blk(256);
+    const size_t lds = (size_t)4 * 2 * inner * sizeof(float);
+    const bool two = inner > 512;
+#define GO(T, DHV, NCHV) hipLaunchKernelGGL((modattn_bwd_kernel<T, DHV, NCHV>), grid, blk, lds, st, p)
+    if (dtype == MMAE_BF16) {
+        if (head_dim == 64) { if (two) GO(bf16, 64, 2); else GO(bf16, 64, 1); } else { if (two) GO(bf16, 32, 2); else GO(bf16, 32, 1); }
+    } else {
+        if (head_dim == 64) { if (two) GO(float, 64, 2); else GO(float, 64, 1); } else { if (two) GO(float, 32, 2); else GO(float, 32, 1); }
+    }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}

@@ -1,0 +1,456 @@
+// HBM-bound row kernels of the fusion-token path (gfx950): fused residual-add + (double) LayerNorm, GEGLU, GELU,
+// row gather / scatter.  One 64-lane wave owns one token row; all loads/stores are 16 B per lane and coalesced.
+//
+// Reference compositions replaced (downstream/instance_segmentation/modeling/multimae/zorro_utils.py):
+//   Block.forward :238-239  x + attn(norm1(x)), x + mlp(norm2(x)) with Attention.norm (:176) / FeedForward[0] (:124)
+//   applied again on top of norm1/norm2 -> LN(LN(x)): both LayerNorms and the preceding residual add are ONE pass here.
+//   LayerNorm :103-110 (gamma, zero beta buffer, eps 1e-5); decoder nn.LayerNorm(eps=1e-6) with bias
+//   (pretraining/multimae/output_adapters_simple.py:75).  GEGLU :115-118 (exact erf GELU, value = first half, gate = second).
+#include "common.hpp"
+#include "mmae_hip.h"
+
+template <typename T> __device__ __forceinline__ f32x4 ld4f(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4f<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4f<bf16>(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4f(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void st4f<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4f<bf16>(bf16* p, const f32x4& v) {
+    bf16x4 o; o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+__device__ __forceinline__ float sum4(const f32x4& v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// ------------------------------------------------------------------------------------------ add + LayerNorm(x2) forward
+struct AddLnFwd {
+    const float* x; const void* delta; float* x_new; void* y;
+    const float* g1; const float* b1; const float* g2; const float* b2;
+    float eps1, eps2; float* stats; long rows; int D;
+};
+
+// NC = number of 256-column chunks held per lane (4 columns per lane per chunk)
+template <typename TD, typename TY, int NC, bool DOUBLE>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(AddLnFwd p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int D = p.D;
+    const float invD = 1.f / (float)D;
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < D) {
+            v[c] = ld4f<float>(p.x + row * D + col);
+            if (p.delta) v[c] += ld4f<TD>(reinterpret_cast<const TD*>(p.delta) + row * D + col);
+            if (p.x_new) st4f<float>(p.x_new + row * D + col, v[c]);
+            s += sum4(v[c]);
+        }
+    }
+    const float m1 = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (col < D) { const f32x4 d = v[c] - m1; q += sum4(d * d); }
+    }
+    const float r1 = rsqrtf(wave_sum(q) * invD + p.eps1);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (col < D) {
+            f32x4 u = (v[c] - m1) * r1 * ld4f<float>(p.g1 + col);
+            if (p.b1) u += ld4f<float>(p.b1 + col);
+            v[c] = u;
+            s2 += sum4(u);
+        }
+    }
+    float m2 = 0.f, r2 = 1.f;
+    if (DOUBLE) {
+        m2 = wave_sum(s2) * invD;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) { const f32x4 d = v[c] - m2; q2 += sum4(d * d); }
+        }
+        r2 = rsqrtf(wave_sum(q2) * invD + p.eps2);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (col < D) {
+            f32x4 o = v[c];
+            if (DOUBLE) {
+                o = (o - m2) * r2 * ld4f<float>(p.g2 + col);
+                if (p.b2) o += ld4f<float>(p.b2 + col);
+            }
+            st4f<TY>(reinterpret_cast<TY*>(p.y) + row * D + col, o);
+        }
+    }
+    if (lane == 0) *reinterpret_cast<f32x4*>(p.stats + row * 4) = f32x4{m1, r1, m2, r2};
+}
+
+// ------------------------------------------------------------------------------------------ add + LayerNorm(x2) backward
+struct AddLnBwd {
+    const float* x_new; const void* gy; const float* gx_up;
+    const float* g1; const float* b1; const float* g2; const float* stats;
+    float* gx; void* gdelta; float* ws;   // ws: (nblk, 4, D) partial column sums [dg1, db1, dg2, db2]
+    long rows; int D;
+};
+
+template <typename TD, typename TY, int NC, bool DOUBLE>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D;
+    const float invD = 1.f / (float)D;
+    f32x4 dg1[NC], db1[NC], dg2[NC], db2[NC], G1[NC], G2[NC], B1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        const f32x4 z{0.f, 0.f, 0.f, 0.f};
+        dg1[c] = z; db1[c] = z; dg2[c] = z; db2[c] = z; G1[c] = z; G2[c] = z; B1[c] = z;
+        if (col < D) {
+            G1[c] = ld4f<float>(p.g1 + col);
+            if (p.b1) B1[c] = ld4f<float>(p.b1 + col);
+            if (DOUBLE) G2[c] = ld4f<float>(p.g2 + col);
+        }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const f32x4 st = *reinterpret_cast<const f32x4*>(p.stats + row * 4);
+        const float m1 = st[0], r1 = st[1], m2 = st[2], r2 = st[3];
+        f32x4 xh[NC], gv[NC];
+        float a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            xh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[c] = xh[c];
+            if (col < D) {
+                xh[c] = (ld4f<float>(p.x_new + row * D + col) - m1) * r1;
+                const f32x4 gy = ld4f<TY>(reinterpret_cast<const TY*>(p.gy) + row * D + col);
+                if (DOUBLE) {
+                    const f32x4 uh = (xh[c] * G1[c] + B1[c] - m2) * r2;
+                    dg2[c] += gy * uh; db2[c] += gy;
+                    const f32x4 guh = gy * G2[c];
+                    gv[c] = guh;
+                    a += sum4(guh); bsum += sum4(guh * uh);
+                } else {
+                    gv[c] = gy;
+                }
+            }
+        }
+        if (DOUBLE) {
+            const float c1 = wave_sum(a) * invD, c2 = wave_sum(bsum) * invD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = 4 * (lane + 64 * c);
+                if (col < D) {
+                    const f32x4 uh = (xh[c] * G1[c] + B1[c] - m2) * r2;
+                    gv[c] = (gv[c] - c1 - uh * c2) * r2;      // grad wrt u
+                }
+            }
+        }
+        float a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) {
+                dg1[c] += gv[c] * xh[c]; db1[c] += gv[c];
+                gv[c] = gv[c] * G1[c];                        // grad wrt xhat
+                a3 += sum4(gv[c]); a4 += sum4(gv[c] * xh[c]);
+            }
+        }
+        const float c3 = wave_sum(a3) * invD, c4 = wave_sum(a4) * invD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) {
+                f32x4 gx = (gv[c] - c3 - xh[c] * c4) * r1;
+                if (p.gx_up) gx += ld4f<float>(p.gx_up + row * D + col);
+                if (p.gx) st4f<float>(p.gx + row * D + col, gx);
+                if (p.gdelta) st4f<TD>(reinterpret_cast<TD*>(p.gdelta) + row * D + col, gx);
+            }
+        }
+    }
+    // block reduction of the four column-sum vectors, one after the other
+#pragma unroll
+    for (int qn = 0; qn < 4; ++qn) {
+        if (!DOUBLE && qn >= 2) break;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) {
+                const f32x4 val = qn == 0 ? dg1[c] : qn == 1 ? db1[c] : qn == 2 ? dg2[c] : db2[c];
+                *reinterpret_cast<f32x4*>(red + wave * D + col) = val;
+            }
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += 256)
+            p.ws[((long)blockIdx.x * 4 + qn) * D + col] = red[col] + red[D + col] + red[2 * D + col] + red[3 * D + col];
+    }
+}
+
+__global__ void colsum_finalize_kernel(const float* ws, int nblk, int D, float* o0, float* o1, float* o2, float* o3) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qn = blockIdx.y;
+    float* out = qn == 0 ? o0 : qn == 1 ? o1 : qn == 2 ? o2 : o3;
+    if (col >= D || !out) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[((long)b * 4 + qn) * D + col];
+    out[col] = s;
+}
+
+template <typename TD, typename TY, bool DOUBLE>
+static int add_ln_fwd_nc(const AddLnFwd& p, hipStream_t st) {
+    const int nc = cdiv(p.D, 256);
+    dim3 grid(cdiv(p.rows, 4)), blk(256);
+    switch (nc) {
+        case 1: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 1, DOUBLE>), grid, blk, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 2, DOUBLE>), grid, blk, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 3, DOUBLE>), grid, blk, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 4, DOUBLE>), grid, blk, 0, st, p); break;
+        default: return MMAE_ERR_ARG;
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+template <typename TD, typename TY, bool DOUBLE>
+static int add_ln_bwd_nc(const AddLnBwd& p, int nblk, hipStream_t st) {
+    const int nc = cdiv(p.D, 256);
+    dim3 grid(nblk), blk(256);
+    const size_t lds = (size_t)4 * p.D * sizeof(float);
+    switch (nc) {
+        case 1: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 1, DOUBLE>), grid, blk, lds, st, p); break;
+        case 2: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 2, DOUBLE>), grid, blk, lds, st, p); break;
+        case 3: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 3, DOUBLE>), grid, blk, lds, st, p); break;
+        case 4: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 4, DOUBLE>), grid, blk, lds, st, p); break;
+        default: return MMAE_ERR_ARG;
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+#define DISPATCH_TD_TY(FN, ...)                                                                         \
+    (dtype_delta == MMAE_BF16                                                                           \
+         ? (dtype_y == MMAE_BF16 ? (dbl ? FN<bf16, bf16, true>(__VA_ARGS__) : FN<bf16, bf16, false>(__VA_ARGS__))    \
+                                 : (dbl ? FN<bf16, float, true>(__VA_ARGS__) : FN<bf16, float, false>(__VA_ARGS__))) \
+         : (dtype_y == MMAE_BF16 ? (dbl ? FN<float, bf16, true>(__VA_ARGS__) : FN<float, bf16, false>(__VA_ARGS__))  \
+                                 : (dbl ? FN<float, float, true>(__VA_ARGS__) : FN<float, float, false>(__VA_ARGS__))))
+
+static bool ok_dtype(int d) { return d == MMAE_F32 || d == MMAE_BF16; }
+
+extern "C" int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, const float* x, const void* delta,
+                               float* x_new, void* y, const float* gamma1, const float* beta1, float eps1,
+                               const float* gamma2, const float* beta2, float eps2, float* stats, void* stream) {
+    if (!ok_dtype(dtype_delta) || !ok_dtype(dtype_y) || rows < 0 || D <= 0 || (D % 4) || D > 1024) return MMAE_ERR_ARG;
+    if (!x || !y || !gamma1 || !stats) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    AddLnFwd p{x, delta, delta ? x_new : nullptr, y, gamma1, beta1, gamma2, beta2, eps1, eps2, stats, rows, D};
+    if (delta && !x_new) return MMAE_ERR_ARG;
+    const bool dbl = gamma2 != nullptr;
+    return DISPATCH_TD_TY(add_ln_fwd_nc, p, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmae_add_ln_bwd_ws_floats(long rows, int D) {
+    long nblk = (rows + 3) / 4; if (nblk > 512) nblk = 512; if (nblk < 1) nblk = 1;
+    return (int)(nblk * 4 * D);
+}
+
+extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy,
+                               const float* gx_up, const float* gamma1, const float* beta1, const float* gamma2,
+                               const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1,
+                               float* dgamma2, float* dbeta2, float* ws, void* stream) {
+    if (!ok_dtype(dtype_delta) || !ok_dtype(dtype_y) || rows < 0 || D <= 0 || (D % 4) || D > 1024) return MMAE_ERR_ARG;
+    if (!x_new || !gy || !gamma1 || !stats || !ws) return MMAE_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long nblk = (rows + 3) / 4; if (nblk > 512) nblk = 512; if (nblk < 1) nblk = 1;
+    AddLnBwd p{x_new, gy, gx_up, gamma1, beta1, gamma2, stats, gx, gdelta, ws, rows, D};
+    const bool dbl = gamma2 != nullptr;
+    int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(D, 256), dbl ? 4 : 2), dim3(256), 0, st, ws, (int)nblk, D,
+                       dgamma1, dbeta1, dgamma2, dbeta2);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ GEGLU / GELU
+template <typename T, int V>
+__global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int F) {
+    const long n = rows * (F / V);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / (F / V);
+        const int c = (int)(i % (F / V)) * V;
+        const T* hv = h + r * 2 * F + c;
+        if (V == 4) {
+            const f32x4 val = ld4f<T>(hv), gate = ld4f<T>(hv + F);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_f(gate[j]) * val[j];
+            st4f<T>(out + r * F + c, o);
+        } else {
+            out[r * F + c] = from_f<T>(gelu_f(to_f(hv[F])) * to_f(hv[0]));
+        }
+    }
+}
+template <typename T, int V>
+__global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ g, T* __restrict__ dh, long rows, int F) {
+    const long n = rows * (F / V);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / (F / V);
+        const int c = (int)(i % (F / V)) * V;
+        const T* hv = h + r * 2 * F + c;
+        T* dv = dh + r * 2 * F + c;
+        if (V == 4) {
+            const f32x4 val = ld4f<T>(hv), gate = ld4f<T>(hv + F), gg = ld4f<T>(g + r * F + c);
+            f32x4 dval, dgate;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dval[j] = gg[j] * gelu_f(gate[j]); dgate[j] = gg[j] * val[j] * gelu_grad_f(gate[j]); }
+            st4f<T>(dv, dval); st4f<T>(dv + F, dgate);
+        } else {
+            const float val = to_f(hv[0]), gate = to_f(hv[F]), gg = to_f(g[r * F + c]);
+            dv[0] = from_f<T>(gg * gelu_f(gate));
+            dv[F] = from_f<T>(gg * val * gelu_grad_f(gate));
+        }
+    }
+}
+template <typename T, int V>
+__global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (long)gridDim.x * blockDim.x * V) {
+        if (V == 4) {
+            const f32x4 v = ld4f<T>(x + i); f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_f(v[j]);
+            st4f<T>(y + i, o);
+        } else y[i] = from_f<T>(gelu_f(to_f(x[i])));
+    }
+}
+template <typename T, int V>
+__global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ dx, long n) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (long)gridDim.x * blockDim.x * V) {
+        if (V == 4) {
+            const f32x4 v = ld4f<T>(x + i), gg = ld4f<T>(g + i); f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gg[j] * gelu_grad_f(v[j]);
+            st4f<T>(dx + i, o);
+        } else dx[i] = from_f<T>(to_f(g[i]) * gelu_grad_f(to_f(x[i])));
+    }
+}
+
+static int ew_grid(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1; return (int)b; }
+
+extern "C" int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || F <= 0 || !h || !out) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool v4 = (F % 4) == 0;
+    const long n = rows * (v4 ? F / 4 : F);
+#define GO(T, V) hipLaunchKernelGGL((geglu_fwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (T*)out, rows, F)
+    if (dtype == MMAE_BF16) { if (v4) GO(bf16, 4); else GO(bf16, 1); } else { if (v4) GO(float, 4); else GO(float, 1); }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+extern "C" int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || F <= 0 || !h || !gout || !dh) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool v4 = (F % 4) == 0;
+    const long n = rows * (v4 ? F / 4 : F);
+#define GO(T, V) hipLaunchKernelGGL((geglu_bwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (const T*)gout, (T*)dh, rows, F)
+    if (dtype == MMAE_BF16) { if (v4) GO(bf16, 4); else GO(bf16, 1); } else { if (v4) GO(float, 4); else GO(float, 1); }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+extern "C" int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* stream) {
+    if (!ok_dtype(dtype) || n < 0 || !x || !y) return MMAE_ERR_ARG;
+    if (n == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool v4 = (n % 4) == 0;
+#define GO(T, V) hipLaunchKernelGGL((gelu_fwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (T*)y, n)
+    if (dtype == MMAE_BF16) { if (v4) GO(bf16, 4); else GO(bf16, 1); } else { if (v4) GO(float, 4); else GO(float, 1); }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+extern "C" int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, void* dx, void* stream) {
+    if (!ok_dtype(dtype) || n < 0 || !x || !g || !dx) return MMAE_ERR_ARG;
+    if (n == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool v4 = (n % 4) == 0;
+#define GO(T, V) hipLaunchKernelGGL((gelu_bwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (const T*)g, (T*)dx, n)
+    if (dtype == MMAE_BF16) { if (v4) GO(bf16, 4); else GO(bf16, 1); } else { if (v4) GO(float, 4); else GO(float, 1); }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ row gather / scatter
+// out[r, :] = src[idx[r], :]   (idx < 0 -> zeros).  W multiple of 4.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx,
+                                                          T* __restrict__ out, long rows, int W, long src_stride, long out_stride) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int s = idx[r];
+    for (int c = 4 * lane; c < W; c += 256) {
+        f32x4 v{0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) v = ld4f<T>(src + (long)s * src_stride + c);
+        st4f<T>(out + r * out_stride + c, v);
+    }
+}
+// dst[idx[r], :] (+)= src[r, :]  for idx[r] >= 0 (and filter[r] == filter_value when a filter is given).  Plain
+// read-modify-write, no atomics: the indices of the rows that pass the filter must be unique within one call.
+template <typename T, bool ACC>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx,
+                                                           T* __restrict__ dst, long rows, int W, long src_stride, long dst_stride,
+                                                           const int* __restrict__ filter, int filter_value) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int d = idx[r];
+    if (d < 0) return;
+    if (filter && filter[r] != filter_value) return;
+    for (int c = 4 * lane; c < W; c += 256) {
+        f32x4 v = ld4f<T>(src + r * src_stride + c);
+        if (ACC) v += ld4f<T>(dst + (long)d * dst_stride + c);
+        st4f<T>(dst + (long)d * dst_stride + c, v);
+    }
+}
+
+extern "C" int mmae_gather_rows(int dtype, long rows, int W, const void* src, long src_stride, const int* idx, void* out,
+                                long out_stride, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || W <= 0 || (W % 4) || !src || !idx || !out || (src_stride % 4) || (out_stride % 4)) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MMAE_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)src, idx, (bf16*)out, rows, W, src_stride, out_stride);
+    else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)src, idx, (float*)out, rows, W, src_stride, out_stride);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+extern "C" int mmae_scatter_rows(int dtype, long rows, int W, const void* src, long src_stride, const int* idx, void* dst,
+                                 long dst_stride, int accumulate, const int* filter, int filter_value, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || W <= 0 || (W % 4) || !src || !idx || !dst || (src_stride % 4) || (dst_stride % 4)) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(rows, 4)), blk(256);
+    if (dtype == MMAE_BF16) {
+        if (accumulate) hipLaunchKernelGGL((scatter_rows_kernel<bf16, true>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        else hipLaunchKernelGGL((scatter_rows_kernel<bf16, false>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+    } else {
+        if (accumulate) hipLaunchKernelGGL((scatter_rows_kernel<float, true>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        else hipLaunchKernelGGL((scatter_rows_kernel<float, false>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}

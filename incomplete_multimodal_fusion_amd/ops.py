@@ -1,0 +1,505 @@
+"""torch.autograd wrappers around the C ABI (include/mmae_hip.h).  Device tensors only; no fallback.
+
+Every Function here launches hand-written gfx950 kernels through ctypes on torch's current HIP stream.  Dense
+projections between them are plain torch matmuls (hipBLASLt) chosen by the callers in multimae/.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, stream
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rowmat(t, cols_needed):
+    """A 2-D (rows, >=cols) view with unit column stride; returns (tensor, row_stride)."""
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor"
+    return t, t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ segments
+class Segments:
+    """Device-side segment descriptors for the masked attention: int32 (B, nseg) start rows and lengths."""
+
+    def __init__(self, start: torch.Tensor, length: torch.Tensor, max_rows: int):
+        assert start.dtype == torch.int32 and length.dtype == torch.int32 and start.shape == length.shape
+        self.start, self.length, self.max_rows = _c(start), _c(length), int(max_rows)
+        self.B, self.nseg = start.shape
+
+    @staticmethod
+    def dense(B: int, n: int, device, nseg: int = 1, row0: int = 0):
+        """Every sample: one attend-all segment of n rows (rows b*n ...)."""
+        start = torch.zeros(B, nseg, dtype=torch.int32, device=device)
+        length = torch.zeros(B, nseg, dtype=torch.int32, device=device)
+        start[:, nseg - 1] = torch.arange(B, dtype=torch.int32, device=device) * n + row0
+        length[:, nseg - 1] = n
+        return Segments(start, length, n)
+
+    @staticmethod
+    def from_types(types: Sequence[int], B: int, nseg: int, device, per_sample_rows: Optional[int] = None):
+        """Host helper (tests / standalone module use): token types of ONE sample, sorted ascending, shared by the
+        batch; rows of sample b start at b * per_sample_rows."""
+        n = len(types)
+        per = n if per_sample_rows is None else per_sample_rows
+        assert list(types) == sorted(types), "tokens must be grouped by type in ascending type order"
+        lens = [sum(1 for t in types if t == s) for s in range(nseg)]
+        starts = [sum(lens[:s]) for s in range(nseg)]
+        st = torch.tensor([[b * per + s0 for s0 in starts] for b in range(B)], dtype=torch.int32, device=device)
+        ln = torch.tensor([lens for _ in range(B)], dtype=torch.int32, device=device)
+        return Segments(st, ln, n)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class _MHA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qt, kvt, qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode):
+        I = H * dh
+        same = kvt is None
+        kv = qt if same else kvt
+        assert qt.dim() == 2 and qt.stride(1) == 1 and kv.dim() == 2 and kv.stride(1) == 1
+        assert qt.dtype == kv.dtype
+        out = torch.empty(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
+        lse = torch.empty(H, qt.shape[0], dtype=torch.float32, device=qt.device)
+        es = qt.element_size()
+        call("mmae_mha_fwd", dt(qt), dh, qseg.B, H, qseg.nseg,
+             ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
+             ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(lse),
+             qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), qt.shape[0],
+             ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length), qseg.max_rows, scale, empty_mode,
+             stream())
+        ctx.save_for_backward(qt, kv, out, lse)
+        ctx.cfg = (qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qt, kv, out, lse = ctx.saved_tensors
+        qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same = ctx.cfg
+        gout = _c(gout)
+        I = H * dh
+        # every row of q / kv belongs to exactly one segment, and the q, k, v column slices are written completely;
+        # columns outside them (none for fused qkv / kv projections) must not exist.
+        assert qt.shape[1] == (3 * I if same else I) and kv.shape[1] == (3 * I if same else 2 * I), \
+            "attention operands must be exactly the fused projection outputs"
+        gq = torch.empty_like(qt)
+        gkv = gq if same else torch.empty_like(kv)
+        delta = torch.empty_like(lse)
+        es = qt.element_size()
+        call("mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
+             ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
+             ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(gout), ptr(lse), ptr(delta),
+             ctypes.c_void_p(gq.data_ptr() + qcol * es), ctypes.c_void_p(gkv.data_ptr() + kcol * es),
+             ctypes.c_void_p(gkv.data_ptr() + vcol * es),
+             qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), gout.stride(0), gq.stride(0), gkv.stride(0),
+             gkv.stride(0), qt.shape[0], ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length),
+             qseg.max_rows, kseg.max_rows, scale, empty_mode, stream())
+        return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None
+
+
+def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv") -> torch.Tensor:
+    """Self attention on a fused projection output qkv (rows, 3*H*dh) laid out [q | k | v] column blocks."""
+    I = H * dh
+    return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0)
+
+
+def mha_cross(q: torch.Tensor, kv: torch.Tensor, H: int, dh: int, qseg: Segments, kseg: Segments, scale: float,
+              empty_mode: int = 0) -> torch.Tensor:
+    """q (rows_q, H*dh), kv (rows_k, 2*H*dh) = [k | v]."""
+    return _MHA.apply(q, kv, 0, 0, H * dh, H, dh, qseg, kseg, scale, empty_mode)
+
+
+# ------------------------------------------------------------------------------------------------ modality attention
+class _ModAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, slot_row, B, P, ns, H, dh, shared_base, scale):
+        I = H * dh
+        assert q.shape == (B * P, I) and kv.shape[1] == 2 * I and q.stride(1) == 1 and kv.stride(1) == 1
+        assert slot_row.dtype == torch.int32 and slot_row.is_contiguous()
+        out = torch.empty(B * P, I, dtype=q.dtype, device=q.device)
+        call("mmae_modattn_fwd", dt(q), dh, B, P, ns, I, ptr(q), q.stride(0), ptr(kv), kv.stride(0), ptr(slot_row),
+             ptr(out), out.stride(0), scale, stream())
+        ctx.save_for_backward(q, kv, slot_row)
+        ctx.cfg = (B, P, ns, H, dh, shared_base, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, kv, slot_row = ctx.saved_tensors
+        B, P, ns, H, dh, shared_base, scale = ctx.cfg
+        gout = _c(gout)
+        gq = torch.empty_like(q)
+        gkv = torch.empty_like(kv)
+        assert kv.shape[0] == shared_base + P, "kv rows must be [token rows | P mask-embedding rows]"
+        call("mmae_modattn_bwd", dt(q), dh, B, P, ns, H * dh, ptr(q), q.stride(0), ptr(kv), kv.stride(0),
+             ptr(slot_row), ptr(gout), gout.stride(0), ptr(gq), gq.stride(0), ptr(gkv), gkv.stride(0), shared_base,
+             scale, stream())
+        return gq, gkv, None, None, None, None, None, None, None, None
+
+
+def modattn(q, kv, slot_row, B, P, ns, H, dh, shared_base, scale):
+    return _ModAttn.apply(q, kv, slot_row, B, P, ns, H, dh, shared_base, scale)
+
+
+# ------------------------------------------------------------------------------------------------ add + LayerNorm
+class _PartsAddLN(torch.autograd.Function):
+    """Several row-parts of the fp32 residual stream -> one contiguous normalised matrix.
+
+    forward(delta, g1, b1, g2, b2, cfg, *xs): part i has rows xs[i] (r_i, D) fp32; cfg.delta_off[i] is the row offset
+    of its delta inside `delta` (or -1: no delta, residual unchanged).
+    Returns (x_new_i for the parts that have a delta ..., y) with y = LN2(LN1(x_new)), rows of all parts concatenated.
+    """
+
+    @staticmethod
+    def forward(ctx, delta, g1, b1, g2, b2, cfg, *xs):
+        eps1, eps2, out_dtype, delta_off = cfg
+        D = xs[0].shape[1]
+        rows = [x.shape[0] for x in xs]
+        total = sum(rows)
+        dev = xs[0].device
+        y = torch.empty(total, D, dtype=out_dtype, device=dev)
+        stats = torch.empty(total, 4, dtype=torch.float32, device=dev)
+        ln_in, outs = [], []
+        r0 = 0
+        ddt = dt(delta) if delta is not None else _lib.F32
+        for x, off in zip(xs, delta_off):
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == D
+            if off >= 0:
+                xn = torch.empty_like(x)
+                dptr = ctypes.c_void_p(delta.data_ptr() + off * D * delta.element_size())
+                outs.append(xn)
+            else:
+                xn, dptr = x, None
+            call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
+                 ctypes.c_void_p(y.data_ptr() + r0 * D * y.element_size()), ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2),
+                 eps2, ctypes.c_void_p(stats.data_ptr() + r0 * 16), stream())
+            ln_in.append(xn)
+            r0 += x.shape[0]
+        ctx.save_for_backward(g1, b1, g2, stats, *ln_in)
+        ctx.meta = (rows, D, delta_off, out_dtype, None if delta is None else (delta.shape, delta.dtype),
+                    b1 is not None, b2 is not None)
+        return (*outs, y)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g1, b1, g2, stats, *ln_in = ctx.saved_tensors
+        rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2 = ctx.meta
+        gy = _c(grads[-1])
+        ups = list(grads[:-1])          # upstream grads of the x_new outputs, in order of the parts that have a delta
+        dev = gy.device
+        gdelta = torch.empty(dmeta[0], dtype=dmeta[1], device=dev) if dmeta is not None else None
+        ddt = dt(dmeta[1]) if dmeta is not None else _lib.F32
+        dbl = g2 is not None
+        acc = [None, None, None, None]
+        gxs = []
+        r0 = 0
+        for i, (xn, n, off) in enumerate(zip(ln_in, rows, delta_off)):
+            up = ups.pop(0) if off >= 0 else None
+            need_gx = ctx.needs_input_grad[6 + i]
+            if n == 0:
+                gxs.append(None)
+                continue
+            gx = torch.empty_like(xn) if need_gx else None
+            part = [torch.empty(D, dtype=torch.float32, device=dev),
+                    torch.empty(D, dtype=torch.float32, device=dev) if has_b1 else None,
+                    torch.empty(D, dtype=torch.float32, device=dev) if dbl else None,
+                    torch.empty(D, dtype=torch.float32, device=dev) if (dbl and has_b2) else None]
+            ws = torch.empty(_lib.lib().mmae_add_ln_bwd_ws_floats(n, D), dtype=torch.float32, device=dev)
+            gd = ctypes.c_void_p(gdelta.data_ptr() + off * D * gdelta.element_size()) if off >= 0 else None
+            call("mmae_add_ln_bwd", ddt, dt(out_dtype), n, D, ptr(xn),
+                 ctypes.c_void_p(gy.data_ptr() + r0 * D * gy.element_size()), ptr(_c(up)) if up is not None else None,
+                 ptr(g1), ptr(b1), ptr(g2), ctypes.c_void_p(stats.data_ptr() + r0 * 16), ptr(gx), gd, ptr(part[0]),
+                 ptr(part[1]), ptr(part[2]), ptr(part[3]), ptr(ws), stream())
+            for k in range(4):
+                if part[k] is not None:
+                    acc[k] = part[k] if acc[k] is None else acc[k] + part[k]
+            gxs.append(gx)
+            r0 += n
+        return (gdelta, acc[0], acc[1], acc[2], acc[3], None, *gxs)
+
+
+def parts_add_ln(xs: List[torch.Tensor], delta: Optional[torch.Tensor], delta_off: List[int], g1, b1=None, g2=None,
+                 b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32):
+    """-> (list of updated residual parts, y).  A part with delta_off < 0 keeps its residual unchanged."""
+    outs = list(_PartsAddLN.apply(delta, g1, b1, g2, b2, (eps1, eps2, out_dtype, tuple(delta_off)), *xs))
+    y = outs.pop()
+    x_news = [outs.pop(0) if off >= 0 else x for x, off in zip(xs, delta_off)]
+    return x_news, y
+
+
+def layernorm(x2d: torch.Tensor, g1, b1=None, g2=None, b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32):
+    """Plain (double) LayerNorm of an fp32 (rows, D) matrix."""
+    _, y = parts_add_ln([x2d], None, [-1], g1, b1, g2, b2, eps1, eps2, out_dtype)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ GEGLU / GELU
+class _GEGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        h = _c(h)
+        F2 = h.shape[-1]
+        assert F2 % 2 == 0
+        rows = h.numel() // F2
+        out = torch.empty(*h.shape[:-1], F2 // 2, dtype=h.dtype, device=h.device)
+        call("mmae_geglu_fwd", dt(h), rows, F2 // 2, ptr(h), ptr(out), stream())
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        g = _c(g)
+        F2 = h.shape[-1]
+        dh = torch.empty_like(h)
+        call("mmae_geglu_bwd", dt(h), h.numel() // F2, F2 // 2, ptr(h), ptr(g), ptr(dh), stream())
+        return dh
+
+
+class _GELU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("mmae_gelu_fwd", dt(x), x.numel(), ptr(x), ptr(y), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _c(g)
+        dx = torch.empty_like(x)
+        call("mmae_gelu_bwd", dt(x), x.numel(), ptr(x), ptr(g), ptr(dx), stream())
+        return dx
+
+
+geglu = _GEGLU.apply
+gelu = _GELU.apply
+
+
+# ------------------------------------------------------------------------------------------------ gather rows
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx, unique, filt, nfilt):
+        assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
+        out = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+        call("mmae_gather_rows", dt(src), idx.numel(), src.shape[1], ptr(src), src.stride(0), ptr(idx), ptr(out),
+             out.stride(0), stream())
+        ctx.save_for_backward(idx, filt)
+        ctx.cfg = (src.shape, unique, nfilt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, filt = ctx.saved_tensors
+        shape, unique, nfilt = ctx.cfg
+        g = _c(g)
+        gs = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        if unique:
+            call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs),
+                 gs.stride(0), 0, None, 0, stream())
+        else:
+            # destination rows repeat across filter classes (modalities) but are unique within one: one pass per class
+            for f in range(nfilt):
+                call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs),
+                     gs.stride(0), 1, ptr(filt), f, stream())
+        return gs, None, None, None, None
+
+
+def gather_rows(src, idx, unique=True, filt=None, nfilt=0):
+    """out[r] = src[idx[r]] (zeros for idx < 0).  Backward scatters; when destination rows repeat, pass a class id
+    per row (`filt`, values 0..nfilt-1) such that rows of one class have unique destinations."""
+    return _GatherRows.apply(src, idx, unique, filt, nfilt)
+
+
+# ------------------------------------------------------------------------------------------------ patches / images
+def patchify_gather(images: Sequence[torch.Tensor], col_offsets: Sequence[int], onehot_offset: int, Kcat: int,
+                    patch: int, tok_mod: Optional[torch.Tensor], tok_patch: Optional[torch.Tensor],
+                    tokens_per_sample: int, out_dtype) -> torch.Tensor:
+    """No gradient (images are data).  images[m]: (B, C_m, H, W) fp32 contiguous."""
+    B, _, H, W = images[0].shape
+    nmod = len(images)
+    imgs = [_c(im.float()) for im in images]
+    arr = (ctypes.c_void_p * nmod)(*[im.data_ptr() for im in imgs])
+    ch = (ctypes.c_int * nmod)(*[im.shape[1] for im in imgs])
+    co = (ctypes.c_int * nmod)(*col_offsets)
+    out = torch.empty(B * tokens_per_sample, Kcat, dtype=out_dtype, device=imgs[0].device)
+    call("mmae_patchify_gather", dt(out_dtype), nmod, ctypes.cast(arr, ctypes.c_void_p),
+         ctypes.cast(ch, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), onehot_offset, Kcat, B, H, W, patch,
+         ptr(tok_mod), ptr(tok_patch), tokens_per_sample, ptr(out), stream())
+    return out
+
+
+class _Unpatchify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, B, C, H, W, patch):
+        tok = _c(tok)
+        img = torch.empty(B, C, H, W, dtype=torch.float32, device=tok.device)
+        call("mmae_unpatchify", dt(tok), B, C, H, W, patch, ptr(tok), ptr(img), stream())
+        ctx.cfg = (tok.dtype, C, patch)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        tdtype, C, patch = ctx.cfg
+        B, _, H, W = g.shape
+        P = (H // patch) * (W // patch)
+        gt = patchify_gather([g], [0], -1, C * patch * patch, patch, None, None, P, tdtype)
+        return gt, None, None, None, None, None
+
+
+def unpatchify(tok, B, C, H, W, patch):
+    return _Unpatchify.apply(tok, B, C, H, W, patch)
+
+
+class _MaskedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, kind, patch, is_tokens, shape):
+        B, C, H, W = shape
+        pred = _c(pred)
+        target = _c(target.float())
+        P = (H // patch) * (W // patch)
+        dev = pred.device
+        if mask is not None:
+            mask = _c(mask.to(torch.int64))
+        partial = torch.empty(B * P, dtype=torch.float32, device=dev)
+        den = torch.empty(B, dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        call("mmae_masked_loss_fwd", dt(pred), int(is_tokens), kind, B, C, H, W, patch, ptr(pred), ptr(target),
+             ptr(mask), ptr(partial), ptr(den), ptr(stats), stream())
+        ctx.save_for_backward(pred, target, mask, den, stats)
+        ctx.cfg = (kind, patch, is_tokens, shape)
+        return stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, mask, den, stats = ctx.saved_tensors
+        kind, patch, is_tokens, (B, C, H, W) = ctx.cfg
+        g = _c(g.float()).reshape(1)
+        gp = torch.empty_like(pred)
+        call("mmae_masked_loss_bwd", dt(pred), int(is_tokens), kind, B, C, H, W, patch, ptr(pred), ptr(target),
+             ptr(mask), ptr(den), ptr(stats), ptr(g), ptr(gp), stream())
+        return gp, None, None, None, None, None, None
+
+
+def masked_loss_image(pred, target, mask, kind: int, patch: int):
+    """pred/target (B,C,H,W); mask (B,P) {0,1} or None.  kind 0 MSE, 1 L1."""
+    return _MaskedLoss.apply(pred.float(), target, mask, kind, patch, False, tuple(pred.shape))
+
+
+def masked_loss_tokens(tok, target, mask, kind: int, patch: int):
+    """Fused unpatchify+loss: tok (B*P, C*patch^2) decoder output in (c ph pw) order, target image (B,C,H,W)."""
+    return _MaskedLoss.apply(tok, target, mask, kind, patch, True, tuple(target.shape))
+
+
+# ------------------------------------------------------------------------------------------------ contrastive heads
+class _Dino(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher, teacher_temp, student_temp):
+        s = _c(student.float()); t = _c(teacher.float())
+        B, D = s.shape
+        ws = torch.empty(B, dtype=torch.float32, device=s.device)
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        call("mmae_dino_loss_fwd", B, D, ptr(s), ptr(t), student_temp, teacher_temp, ptr(ws), ptr(loss), stream())
+        ctx.save_for_backward(s, t)
+        ctx.cfg = (teacher_temp, student_temp, student.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t = ctx.saved_tensors
+        teacher_temp, student_temp, sdtype = ctx.cfg
+        g = _c(g.float()).reshape(1)
+        gs = torch.empty_like(s)
+        call("mmae_dino_loss_bwd", s.shape[0], s.shape[1], ptr(s), ptr(t), student_temp, teacher_temp, ptr(g), ptr(gs),
+             stream())
+        return gs.to(sdtype), None, None, None
+
+
+def dino_loss(student, teacher, teacher_temp=0.04, student_temp=0.1):
+    return _Dino.apply(student, teacher, teacher_temp, student_temp)
+
+
+class _HardNeg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o1, o2, tau_plus, beta, temperature):
+        a = _c(o1.float()); b = _c(o2.float())
+        B, D = a.shape
+        ws = torch.empty(_lib.lib().mmae_hardneg_ws_floats(B, D), dtype=torch.float32, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        call("mmae_hardneg_loss_fwd", B, D, ptr(a), ptr(b), tau_plus, beta, temperature, ptr(ws), ptr(loss), stream())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (tau_plus, beta, temperature, o1.dtype, o2.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        tau_plus, beta, temperature, d1, d2 = ctx.cfg
+        B, D = a.shape
+        g = _c(g.float()).reshape(1)
+        ws = torch.empty(_lib.lib().mmae_hardneg_ws_floats(B, D), dtype=torch.float32, device=a.device)
+        g1 = torch.empty_like(a); g2 = torch.empty_like(b)
+        call("mmae_hardneg_loss_bwd", B, D, ptr(a), ptr(b), tau_plus, beta, temperature, ptr(ws), ptr(g), ptr(g1),
+             ptr(g2), stream())
+        return g1.to(d1), g2.to(d2), None, None, None
+
+
+def hardneg_loss(o1, o2, tau_plus=0.1, beta=1.0, temperature=0.5):
+    return _HardNeg.apply(o1, o2, tau_plus, beta, temperature)
+
+
+# ------------------------------------------------------------------------------------------------ mask bookkeeping
+def masks_from_draws(dirichlet, noise, noise_all, N: int):
+    """dirichlet (R,M) f32, noise (R,M,P) f32, noise_all (R,M*P) f32 on device ->
+    mask_all (R,M*P) int64, ids_keep (R,N) int64, ids_restore (R,M*P) int64."""
+    R, M, P = noise.shape
+    dev = noise.device
+    mask_all = torch.empty(R, M * P, dtype=torch.int64, device=dev)
+    ids_keep = torch.empty(R, N, dtype=torch.int64, device=dev)
+    ids_restore = torch.empty(R, M * P, dtype=torch.int64, device=dev)
+    call("mmae_masks_from_draws", R, M, P, N, ptr(_c(dirichlet.float())), ptr(_c(noise.float())),
+         ptr(_c(noise_all.float())), ptr(mask_all), ptr(ids_keep), ptr(ids_restore), stream())
+    return mask_all, ids_keep, ids_restore
+
+
+class Descriptors:
+    """Device-side int32 descriptors of one step (csrc/masks.hip).  Row space: [B*N tokens | B*P fusion | P mask-emb]."""
+
+    NAMES = ["enc_start", "enc_len", "tok_mod", "tok_patch", "tok_pe", "tok_fus", "slot_row", "pool_qstart",
+             "pool_qlen", "ctr_qstart", "ctr_qlen", "ctr_kstart", "ctr_klen", "status"]
+
+    def __init__(self, mask_all: torch.Tensor, B: int, M: int, P: int, N: int):
+        R = mask_all.shape[0]
+        assert mask_all.dtype == torch.int64 and mask_all.shape[1] == M * P and R in (1, B)
+        off = (ctypes.c_long * 15)()
+        total = _lib.lib().mmae_descriptor_layout(B, M, P, N, ctypes.cast(off, ctypes.c_void_p))
+        self.buf = torch.empty(total, dtype=torch.int32, device=mask_all.device)
+        call("mmae_build_descriptors", B, R, M, P, N, ptr(_c(mask_all)), ptr(self.buf), stream())
+        self.B, self.M, self.P, self.N = B, M, P, N
+        shapes = {"enc_start": (B, M + 1), "enc_len": (B, M + 1), "slot_row": (B * P, M + 1)}
+        for i, name in enumerate(self.NAMES):
+            v = self.buf[off[i]:off[i + 1]]
+            if name in shapes:
+                v = v.view(*shapes[name])
+            elif name.startswith("pool_") or name.startswith("ctr_"):
+                v = v.view(B, M + 1)
+            setattr(self, name, v)
+        S = N + P
+        self.enc_seg = Segments(self.enc_start, self.enc_len, S)
+        self.pool_q = Segments(self.pool_qstart, self.pool_qlen, M + 1)
+        self.ctr_q = Segments(self.ctr_qstart, self.ctr_qlen, M)
+        self.ctr_k = Segments(self.ctr_kstart, self.ctr_klen, N)
+        self.fus_base = B * N
+        self.shared_base = B * N + B * P
+
+    def check(self):
+        """Host sync: raises if some sample's kept-token count differs from num_encoded_tokens."""
+        bad = int(self.status[0].item())
+        if bad:
+            raise AssertionError("%d sample(s): number of kept tokens != num_encoded_tokens" % bad)

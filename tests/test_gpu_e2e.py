@@ -1,0 +1,110 @@
+"""GPU end-to-end parity of the native MultiMAE path: golden fixtures from the reference (tiny config, incl. a dropped
+modality) and the CPU oracle on a larger seeded config (multi-tile attention, ViT-like widths)."""
+import pytest
+import torch
+
+from oracle import mmae_oracle as O
+from tests.test_cabi_symbols import build_model
+from tests.test_gpu_kernels import DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+def native_step(model, x, masks, N, fused, autocast):
+    from incomplete_multimodal_fusion_amd.pretrain import step_losses
+    model.fuse_unpatchify_loss = fused
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        out = model(x, task_masks=masks, num_encoded_tokens=N)
+        task_losses, loss_contra, loss = step_losses(out, x, masks, patch_size=16)
+    return out, task_losses, loss_contra, loss
+
+
+@pytest.mark.parametrize("case", ["split", "dropdem", "onlys2"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_fused", "bf16"])
+def test_e2e_golden(g_e2e, case, mode):
+    cfg = g_e2e.json("config")
+    model = build_model(cfg, cfg["channels"])
+    model.load_state_dict(g_e2e.sub("state"), strict=True)
+    model.to(DEV).train()
+    x = {k: v.to(DEV) for k, v in g_e2e.sub("x").items()}
+    c = g_e2e.sub("case_" + case)
+    masks = {d: c["mask/" + d].to(DEV) for d in O.DOMAINS}
+    N = int(c["N"])
+    autocast = mode == "bf16"
+    tol = 1e-3 if not autocast else 1e-2
+    out, task_losses, loss_contra, loss = native_step(model, x, masks, N, mode == "fp32_fused", autocast)
+    preds, tm, pooled, ori, fus, r1, r2, r3 = out
+    for d in O.DOMAINS:
+        img = preds[d].image() if hasattr(preds[d], "image") else preds[d]
+        close(img, c["pred/" + d], tol * (3 if autocast else 1), "pred " + d)
+        close(task_losses[d], c["task_loss/" + d], tol, "loss " + d)
+        assert torch.equal(tm[d].cpu(), c["mask/" + d])
+    close(pooled, c["pooled"], tol * (3 if autocast else 1), "pooled"); close(ori, c["ori_tokens"], tol * (3 if autocast else 1), "ori")
+    close(fus, c["fusion_tokens"], tol * (3 if autocast else 1), "fusion")
+    for r, k in ((r1, "ret_s1"), (r2, "ret_s2"), (r3, "ret_dem")):
+        assert r.shape == c[k].shape
+        close(r, c[k], tol * (3 if autocast else 1), k)
+    close(loss_contra, c["loss_contra"], tol, "loss_contra"); close(loss, c["loss"], tol, "loss")
+    gnames = [k[5:] for k in c if k.startswith("grad/")]
+    if not gnames:
+        return
+    loss.backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for n in gnames:
+        assert params[n].grad is not None, "no grad for " + n
+        ref = c["grad/" + n]
+        close(params[n].grad, ref, tol * (10 if autocast else 2), "grad " + n)
+    for n, p in params.items():          # the 7 parameters that never receive a gradient in the reference
+        if p.requires_grad and n not in gnames:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_e2e_vs_oracle_multitile(mode):
+    """256x256 tiles (P=256, N=384, S=640: several 64-row attention tiles, uneven modality split), D=128, 2 heads of
+    64, depth 2, decoder 64/1/2; the oracle runs the same weights on CPU in fp32."""
+    torch.manual_seed(11)
+    cfg = dict(dim_tokens=128, depth=2, dim_head=64, heads=2, image_size=256, patch_size=16, decoder_dim=64,
+               decoder_depth=1, decoder_heads=2)
+    channels = (("s1", 1), ("s2", 3), ("dem", 1))
+    model = build_model(cfg, channels)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad and (n.endswith("gamma") or "norm" in n and n.endswith("weight")):
+                p.add_(0.2 * torch.randn_like(p))
+        model.mask_embedding.add_(0.05 * torch.randn_like(model.mask_embedding))
+    B, P, N = 2, 256, 384
+    x = {d: torch.randn(B, c, 256, 256) for d, c in channels}
+    keep = {"s1": 201, "s2": 64, "dem": 119}
+    masks = {}
+    for d, k in keep.items():
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("pos_emb") and not k.endswith("beta"))
+         for k, v in state.items()}
+    out_r, (tl_r, lc_r, loss_r) = O.train_step_loss(p, x, masks, N, cfg["heads"], cfg["decoder_heads"], 16)
+    loss_r.backward()
+    model.to(DEV).train()
+    autocast = mode == "bf16"
+    tol = 1e-3 if not autocast else 1e-2
+    xd = {k: v.to(DEV) for k, v in x.items()}; md = {k: v.to(DEV) for k, v in masks.items()}
+    out, tl, lc, loss = native_step(model, xd, md, N, True, autocast)
+    for d in O.DOMAINS:
+        close(out[0][d].image(), out_r[0][d], tol * (4 if autocast else 1), "pred " + d)
+        close(tl[d], tl_r[d], tol, "loss " + d)
+    close(out[2], out_r[2], tol * (4 if autocast else 1), "pooled"); close(out[3], out_r[3], tol * (4 if autocast else 1), "ori")
+    close(out[4], out_r[4], tol * (4 if autocast else 1), "fusion")
+    close(lc, lc_r, tol, "contra"); close(loss, loss_r, tol, "loss")
+    loss.backward()
+    bad = []
+    for n, prm in model.named_parameters():
+        ref = p[n].grad
+        if ref is None:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
+            continue
+        err = float((prm.grad.double().cpu() - ref.double()).abs().max()); sc = float(ref.abs().max())
+        if err > tol * (10 if autocast else 2) * max(sc, 1e-6):
+            bad.append((n, err, sc))
+    assert not bad, bad[:8]

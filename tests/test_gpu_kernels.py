@@ -1,0 +1,402 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every HIP kernel, called through the C ABI, against
+  (a) the committed golden fixtures generated from the reference (tests/golden, oracle/make_golden.py), and
+  (b) the CPU oracle (oracle/mmae_oracle.py) / an fp64 dense restatement on seeded random inputs at larger, ragged sizes.
+Tolerances (north_star): fp32 1e-3, bf16 1e-2, relative to max|reference|; integer bookkeeping bit-exact."""
+import math
+
+import pytest
+import torch
+
+from oracle import mmae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+# fp32 kernels are far more accurate than the contract; a tighter internal bar catches indexing slips early
+TIGHT = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2}
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert not torch.isnan(a).any(), what + ": NaN in result"
+    if b.numel() == 0:
+        return
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "%s: max err %.3e, scale %.3e, tol %.1e" % (what, err, scale, tol)
+
+
+def dev(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+def load_module(mod, weights):
+    missing, unexpected = mod.load_state_dict(weights, strict=True)
+    assert not missing and not unexpected
+    return mod.to(DEV)
+
+
+def W(c):
+    return {k[2:]: v for k, v in c.items() if k.startswith("w.")}
+
+
+def check_param_grads(mod, c, tol, prefix="gw."):
+    for n, p in mod.named_parameters():
+        key = prefix + n
+        if key in c:
+            assert p.grad is not None, n
+            close(p.grad, c[key], tol, "grad " + n)
+
+
+# ---------------------------------------------------------------------------------------------- golden: per-module
+def test_layernorm_golden(g_ops):
+    from incomplete_multimodal_fusion_amd.multimae.zorro_utils import LayerNorm
+    c = g_ops.sub("layernorm")
+    ln = LayerNorm(32).to(DEV)
+    ln.gamma.data.copy_(c["gamma"])
+    x = c["x"].to(DEV).requires_grad_()
+    y = ln(x)
+    close(y, c["y"], TIGHT[torch.float32], "y")
+    y.backward(c["g"].to(DEV))
+    close(x.grad, c["gx"], TIGHT[torch.float32], "gx")
+    close(ln.gamma.grad, c["ggamma"], TIGHT[torch.float32], "ggamma")
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_attention_golden(g_ops, autocast):
+    from incomplete_multimodal_fusion_amd.multimae.zorro_utils import Attention
+    T = torch.bfloat16 if autocast else torch.float32
+    tol = TIGHT[T]
+    c = g_ops.sub("attn_self")
+    attn = load_module(Attention(dim=32, dim_head=32, heads=2), W(c))
+    x = c["x"].to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = attn(x, attn_mask=c["mask"].to(DEV))
+    close(y, c["y"], tol, "self masked y")
+    y.backward(c["g"].to(DEV).to(y.dtype))
+    close(x.grad, c["gx"], tol, "gx")
+    check_param_grads(attn, c, tol)
+    # unmasked
+    attn.zero_grad(); x.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = attn(x)
+    c2 = g_ops.sub("attn_self_nomask")
+    close(y, c2["y"], tol, "self nomask y")
+    y.backward(c["g"].to(DEV).to(y.dtype))
+    close(x.grad, c2["gx"], tol, "gx nomask")
+    # pool-style cross attention with a fully masked row (uniform attention) -------------------------------
+    cp = g_ops.sub("attn_pool")
+    attn.zero_grad()
+    q = cp["q"].to(DEV).requires_grad_(); ctx = cp["ctx"].to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = attn(q, context=ctx, attn_mask=cp["mask"].to(DEV))
+    close(y, cp["y"], tol, "pool y")
+    y.backward(cp["g"].to(DEV).to(y.dtype))
+    close(q.grad, cp["gq"], tol, "pool gq"); close(ctx.grad, cp["gctx"], tol, "pool gctx")
+    check_param_grads(attn, cp, tol)
+    # single query, no mask; and empty context -> zeros ----------------------------------------------------
+    c1 = g_ops.sub("attn_cross1")
+    q = c1["q"].to(DEV).requires_grad_(); ctx = c1["ctx"].to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = attn(q, context=ctx)
+    close(y, c1["y"], tol, "cross1 y")
+    y.backward(c1["g"].to(DEV).to(y.dtype))
+    close(q.grad, c1["gq"], tol, "cross1 gq"); close(ctx.grad, c1["gctx"], tol, "cross1 gctx")
+    y = attn(q, context=torch.zeros(2, 0, 32, device=DEV))
+    close(y, g_ops.sub("attn_cross_empty")["y"], tol, "empty ctx")
+
+
+@pytest.mark.parametrize("case", ["feedforward", "mlp", "block", "block_fusion"])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_blocks_golden(g_ops, case, autocast):
+    from incomplete_multimodal_fusion_amd.multimae import zorro_utils as Z
+    T = torch.bfloat16 if autocast else torch.float32
+    tol = TIGHT[T] * (2 if autocast else 1)
+    c = g_ops.sub(case)
+    mod = {"feedforward": lambda: Z.FeedForward(dim=32, mult=4),
+           "mlp": lambda: Z.Mlp(in_features=32, hidden_features=128),
+           "block": lambda: Z.Block(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=Z.LayerNorm),
+           "block_fusion": lambda: Z.Block_Fusion(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=Z.LayerNorm)}[case]()
+    mod = load_module(mod, W(c))
+    x = c["x"].to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = mod(x, c["mask"].to(DEV)) if case == "block" else mod(x)
+    close(y, c["y"], tol, case + " y")
+    y.backward(c["g"].to(DEV).to(y.dtype))
+    close(x.grad, c["gx"], tol, case + " gx")
+    check_param_grads(mod, c, tol)
+
+
+def test_adapters_golden(g_ops):
+    from incomplete_multimodal_fusion_amd.multimae import FusionInputAdapter, PatchedInputAdapter, SpatialOutputAdapter
+    tol = TIGHT[torch.float32]
+    c = g_ops.sub("patched_input")
+    pia = load_module(PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32), W(c))
+    y = pia(c["x"].to(DEV))
+    close(y, c["y"], tol, "patched y")
+    y.backward(c["g"].to(DEV))
+    close(pia.proj.weight.grad, c["gweight"], tol, "gweight"); close(pia.proj.bias.grad, c["gbias"], tol, "gbias")
+    c = g_ops.sub("fusion_input")
+    fia = load_module(FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32), W(c))
+    close(fia(c["x"].to(DEV)), c["y"], 1e-6, "fusion adapter")
+    c = g_ops.sub("spatial_output")
+    soa = load_module(SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens_enc=32,
+                                           dim_tokens=64, depth=2, num_heads=2, image_size=32, task="s2",
+                                           context_tasks=["s1", "s2", "dem"]), W(c))
+    enc = c["enc"].to(DEV).requires_grad_()
+    y = soa(enc, {"image_size": (32, 32)}, None, None)
+    close(y, c["y"], tol, "decoder y")
+    y.backward(c["g"].to(DEV))
+    close(enc.grad, c["genc"], tol, "genc")
+    check_param_grads(soa, c, tol)
+    for n, p in soa.named_parameters():          # cross-task embeddings and pos_emb never get a gradient
+        if n.startswith("task_embeddings.") and not n.endswith(".s2"):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["mse", "l1"])
+def test_masked_losses_golden(g_ops, kind):
+    from incomplete_multimodal_fusion_amd.multimae import MaskedL1Loss, MaskedMSELoss
+    cls = MaskedMSELoss if kind == "mse" else MaskedL1Loss
+    tol = TIGHT[torch.float32]
+    c = g_ops.sub("masked_" + kind)
+    pred = c["pred"].to(DEV).requires_grad_(); tgt = c["tgt"].to(DEV); mask = c["mask"].to(DEV)
+    l = cls(patch_size=8, stride=1)(pred, tgt, mask=mask)
+    close(l, c["loss"], tol, "loss")
+    l.backward()
+    ref_g = torch.nan_to_num(c["gpred"], nan=0.0)       # reference: NaN grads for the sample with an empty mask row
+    assert torch.isnan(c["gpred"][2]).all() and not torch.isnan(c["gpred"][:2]).any()
+    close(pred.grad, ref_g, tol, "gpred")
+    c2 = g_ops.sub("masked_%s_nomask" % kind)
+    pred.grad = None
+    l = cls(patch_size=8, stride=1)(pred, tgt, mask=None)
+    close(l, c2["loss"], tol, "loss nomask"); l.backward(); close(pred.grad, c2["gpred"], tol, "gpred nomask")
+    l0 = cls(patch_size=8, stride=1)(pred, tgt, mask=torch.zeros(3, 16, dtype=torch.long, device=DEV))
+    assert float(l0) == 0.0
+    c4 = g_ops.sub("masked_%s_normpix" % kind)
+    pred.grad = None
+    l = cls(patch_size=8, stride=1, norm_pix=True)(pred, tgt, mask=mask)
+    close(l, c4["loss"], tol, "loss normpix"); l.backward()
+    close(pred.grad, torch.nan_to_num(c4["gpred"], nan=0.0), tol, "gpred normpix")
+    # fused token form == image form
+    from incomplete_multimodal_fusion_amd import ops
+    tok = torch.randn(3 * 16, 3 * 64, device=DEV, requires_grad=True)
+    img = ops.unpatchify(tok, 3, 3, 32, 32, 8)
+    li = cls(patch_size=8, stride=1)(img, tgt, mask=mask)
+    (gi,) = torch.autograd.grad(li, tok)
+    tok2 = tok.detach().clone().requires_grad_()
+    lt = cls(patch_size=8, stride=1).forward_tokens(tok2, tgt, mask=mask)
+    lt.backward()
+    close(lt, li, 1e-6, "fused loss"); close(tok2.grad, gi, 1e-6, "fused grad")
+
+
+def test_contrastive_golden(g_ops):
+    from incomplete_multimodal_fusion_amd.multimae import HardNegtive_loss, dino_loss_func
+    tol = TIGHT[torch.float32]
+    c = g_ops.sub("dino")
+    s = c["student"].to(DEV).requires_grad_(); t = c["teacher"].to(DEV).requires_grad_()
+    l = dino_loss_func(s, t)
+    close(l, c["loss"], tol, "dino"); l.backward()
+    close(s.grad, c["gstudent"], tol, "dino gs")
+    assert t.grad is None
+    c = g_ops.sub("hardneg")
+    o1 = c["out_1"].to(DEV).requires_grad_(); o2 = c["out_2"].to(DEV).requires_grad_()
+    l = HardNegtive_loss()(o1, o2)
+    close(l, c["loss"], tol, "hardneg"); l.backward()
+    close(o1.grad, c["g1"], tol, "hardneg g1"); close(o2.grad, c["g2"], tol, "hardneg g2")
+
+
+# ---------------------------------------------------------------------------------------------- bookkeeping: bit exact
+def test_masks_from_draws_bit_exact(g_masks):
+    from incomplete_multimodal_fusion_amd import ops
+    for name in g_masks.json("cases"):
+        c = g_masks.sub(name)
+        N, B, P = int(c["N"]), int(c["B"]), int(c["P"])
+        mask_all, ids_keep, ids_restore = ops.masks_from_draws(c["dirichlet"].to(DEV), c["noise"][None].to(DEV),
+                                                               c["noise_all"].to(DEV), N)
+        ref_all = torch.cat([c["task_mask." + d] for d in O.DOMAINS], dim=1)
+        assert torch.equal(mask_all.cpu().repeat(B, 1), ref_all), name
+        assert torch.equal(ids_keep.cpu().repeat(B, 1), c["ids_keep"]), name
+        assert torch.equal(ids_restore.cpu().repeat(B, 1), c["ids_restore"]), name
+        # descriptors against the oracle's nonzero()-based bookkeeping
+        d = ops.Descriptors(mask_all, B, 3, P, N)
+        d.check()
+        m_idx, types, zorro, pool = O.bookkeeping([mask_all[0, i * P:(i + 1) * P].cpu() for i in range(3)], P)
+        lens = [len(i) for i in m_idx]
+        assert d.enc_len.cpu().tolist() == [lens + [P]] * B
+        assert d.tok_patch.cpu().view(B, N)[0].tolist() == torch.cat(m_idx).tolist()
+        assert d.tok_mod.cpu().view(B, N)[-1].tolist() == types[:N].tolist()
+        slot = d.slot_row.cpu().view(B, P, 4)
+        for m in range(3):
+            kept = torch.zeros(P, dtype=torch.bool); kept[m_idx[m]] = True
+            assert ((slot[0, :, m] < B * N) == kept).all()
+            assert (slot[B - 1, ~kept, m] == B * N + B * P + torch.arange(P)[~kept]).all()
+        assert (slot[B - 1, :, 3] == B * N + (B - 1) * P + torch.arange(P)).all()
+
+
+def test_masks_ties_are_stable():
+    from incomplete_multimodal_fusion_amd import ops
+    P, N = 16, 20
+    noise = torch.zeros(1, 3, P); noise_all = torch.zeros(1, 3 * P)       # all ties
+    dirichlet = torch.tensor([[0.5, 0.25, 0.25]])
+    got = ops.masks_from_draws(dirichlet.to(DEV), noise.to(DEV), noise_all.to(DEV), N)
+    exp = O.masks_from_draws(dirichlet, noise, noise_all, N)
+    for a, b in zip(got, exp):
+        assert torch.equal(a.cpu(), b)
+
+
+# ---------------------------------------------------------------------------------------------- attention kernel, ragged
+def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
+    """fp64 CPU restatement of the segment rule on per-sample row ranges; q,k,v (rows, H, dh) double with grad."""
+    out = torch.zeros_like(q)
+    B, nseg = qseg[0].shape
+    for b in range(B):
+        krows = torch.cat([torch.arange(kseg[0][b, s], kseg[0][b, s] + kseg[1][b, s]) for s in range(nseg)])
+        ktype = torch.cat([torch.full((int(kseg[1][b, s]),), s) for s in range(nseg)])
+        for s in range(nseg):
+            qr = torch.arange(qseg[0][b, s], qseg[0][b, s] + qseg[1][b, s])
+            if len(qr) == 0 or len(krows) == 0:
+                continue
+            allow = torch.ones(len(krows), dtype=torch.bool) if s == nseg - 1 else (ktype == s)
+            if not allow.any():
+                if empty_mode == 1:
+                    continue
+                sim = torch.zeros(q.shape[1], len(qr), len(krows), dtype=q.dtype)     # uniform, no grad to q/k
+            else:
+                sim = torch.einsum("ihd,jhd->hij", q[qr], k[krows]) * scale
+                sim = sim.masked_fill(~allow[None, None, :], -1e300)
+            p = torch.softmax(sim, dim=-1)
+            out = out.index_add(0, qr, torch.einsum("hij,jhd->ihd", p, v[krows]))
+    return out
+
+
+@pytest.mark.parametrize("T,dh", [(torch.float32, 64), (torch.float32, 32), (torch.bfloat16, 64), (torch.bfloat16, 32)])
+@pytest.mark.parametrize("empty_mode", [0, 1])
+def test_mha_kernel_ragged_segments(T, dh, empty_mode):
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(3)
+    H, nseg = 3, 4
+    I = H * dh
+    # per-sample different lengths, crossing 64-row tile boundaries, with empty segments (dropped modalities)
+    qlens = torch.tensor([[70, 1, 130, 65], [0, 64, 63, 129], [5, 0, 0, 3]], dtype=torch.int32)
+    klens = torch.tensor([[70, 0, 131, 65], [3, 64, 0, 200], [0, 0, 0, 0]], dtype=torch.int32)
+    B = qlens.shape[0]
+
+    def starts(lens, gap):
+        st = torch.zeros_like(lens); r = 0
+        for b in range(B):
+            for s in range(nseg):
+                st[b, s] = r; r += int(lens[b, s]) + gap
+        return st, r
+    qst, nq = starts(qlens, 0)
+    kst, nk = starts(klens, 0)
+    q = torch.randn(nq, I); kv = torch.randn(nk, 2 * I); g = torch.randn(nq, I)
+    qd = q.to(DEV, T).requires_grad_(); kvd = kv.to(DEV, T).requires_grad_()
+    qseg = ops.Segments(qst.to(DEV), qlens.to(DEV), int(qlens.sum(1).max()))
+    kseg = ops.Segments(kst.to(DEV), klens.to(DEV), int(klens.sum(1).max()))
+    scale = dh ** -0.5
+    out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode)
+    out.backward(g.to(DEV, T))
+    # reference on what the kernel actually saw (bf16-rounded inputs), fp64
+    q64 = qd.detach().cpu().double().reshape(nq, H, dh).requires_grad_()
+    kv64 = kvd.detach().cpu().double()
+    k64 = kv64[:, :I].reshape(nk, H, dh).clone().requires_grad_(); v64 = kv64[:, I:].reshape(nk, H, dh).clone().requires_grad_()
+    ref = dense_attention_ref(q64, k64, v64, (qst, qlens), (kst, klens), scale, empty_mode)
+    ref.backward(g.to(T).double().reshape(nq, H, dh))
+    tol = 2e-5 if T == torch.float32 else 1e-2
+    close(out, ref.reshape(nq, I), tol, "out")
+    close(qd.grad, q64.grad.reshape(nq, I), tol * 2, "dq")
+    close(kvd.grad[:, :I], k64.grad.reshape(nk, I), tol * 2, "dk")
+    close(kvd.grad[:, I:], v64.grad.reshape(nk, I), tol * 2, "dv")
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+def test_mha_online_softmax_rescale_branch(T):
+    """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path)."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(5)
+    H, dh, n = 1, 64, 300
+    q = torch.randn(n, dh); k = torch.randn(n, dh) * 0.1; v = torch.randn(n, dh)
+    for j, amp in ((70, 4.0), (140, 9.0), (299, 20.0)):
+        k[j] = q[10] * amp / q[10].norm()
+    qkv = torch.cat([q, k, v], dim=1).to(DEV, T).requires_grad_()
+    seg = ops.Segments.dense(1, n, DEV)
+    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+    out.sum().backward()
+    x = qkv.detach().cpu().double().requires_grad_()
+    qq, kk, vv = x[:, :dh], x[:, dh:2 * dh], x[:, 2 * dh:]
+    ref = torch.softmax(qq @ kk.t() * dh ** -0.5, dim=-1) @ vv
+    ref.sum().backward()
+    tol = 2e-5 if T == torch.float32 else 1e-2
+    close(out, ref, tol, "out"); close(qkv.grad, x.grad, tol * 2, "grads")
+
+
+# ---------------------------------------------------------------------------------------------- row kernels, big + odd sizes
+@pytest.mark.parametrize("D", [768, 1024, 48])
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+def test_add_double_ln_vs_oracle(D, T):
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(1)
+    r1, r2 = 37, 130
+    x1 = torch.randn(r1, D); x2 = torch.randn(r2, D) * 3 + 1
+    delta = torch.randn(r1 + r2, D).to(T)
+    g1 = torch.rand(D) + 0.5; g2 = torch.rand(D) + 0.5; gy = torch.randn(r1 + r2, D).to(T); gup = torch.randn(r2, D)
+    xs = [x1.to(DEV).requires_grad_(), x2.to(DEV).requires_grad_()]
+    dd = delta.to(DEV).requires_grad_(); G1 = g1.to(DEV).requires_grad_(); G2 = g2.to(DEV).requires_grad_()
+    (n1, n2), y = ops.parts_add_ln(xs, dd, [0, r1], G1, None, G2, None, out_dtype=T)
+    (y.float() * gy.to(DEV).float()).sum().backward(retain_graph=True)
+    (n2 * gup.to(DEV)).sum().backward()
+    X = torch.cat([x1, x2]).double().requires_grad_(); Dl = delta.double().requires_grad_()
+    A = g1.double().requires_grad_(); Bg = g2.double().requires_grad_()
+    xn = X + Dl
+    yr = O.zorro_layernorm(O.zorro_layernorm(xn, A), Bg)
+    ((yr * gy.double()).sum() + (xn[r1:] * gup.double()).sum()).backward()
+    tol = 2e-5 if T == torch.float32 else 1e-2
+    close(y, yr, tol, "y"); close(torch.cat([n1, n2]), xn, 1e-6, "x_new")
+    close(torch.cat([xs[0].grad, xs[1].grad]), X.grad, tol * 2, "gx"); close(dd.grad, Dl.grad, tol * 2, "gdelta")
+    close(G1.grad, A.grad, tol * 4, "dgamma1"); close(G2.grad, Bg.grad, tol * 4, "dgamma2")
+
+
+@pytest.mark.parametrize("F", [2048, 85])
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+def test_geglu_gelu(F, T):
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(2)
+    h = torch.randn(77, 2 * F).to(T); g = torch.randn(77, F).to(T)
+    hd = h.to(DEV).requires_grad_()
+    out = ops.geglu(hd); out.backward(g.to(DEV))
+    hr = h.double().requires_grad_()
+    ref = O.gelu_erf(hr[:, F:]) * hr[:, :F]; ref.backward(g.double())
+    tol = 1e-5 if T == torch.float32 else 1e-2
+    close(out, ref, tol, "geglu"); close(hd.grad, hr.grad, tol, "geglu grad")
+    xd = h.to(DEV).requires_grad_(); y = ops.gelu(xd); y.backward(torch.ones_like(y))
+    xr = h.double().requires_grad_(); yr = O.gelu_erf(xr); yr.sum().backward()
+    close(y, yr, tol, "gelu"); close(xd.grad, xr.grad, tol, "gelu grad")
+
+
+def test_patchify_unpatchify_roundtrip_exact():
+    """Size-independent property at the full tile size: unpatchify(patchify_dense(x)) == x bit for bit, and
+    patchify_gather picks exactly the kept patches (integer-exact data movement)."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(0)
+    B, H, Wd, ps = 3, 256, 256, 16
+    imgs = [torch.randn(B, c, H, Wd, device=DEV) for c in (1, 3, 1)]
+    for im in imgs:
+        C = im.shape[1]
+        tok = ops.patchify_gather([im], [0], -1, C * ps * ps, ps, None, None, 256, torch.float32)
+        ref = im.reshape(B, C, 16, ps, 16, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * 256, C * ps * ps)
+        assert torch.equal(tok, ref)
+        assert torch.equal(ops.unpatchify(tok, B, C, H, Wd, ps), im)
+    N = 40
+    tok_mod = torch.randint(0, 3, (B * N,), dtype=torch.int32, device=DEV)
+    tok_patch = torch.randint(0, 256, (B * N,), dtype=torch.int32, device=DEV)
+    Ks = [256, 768, 256]; koff = [0, 256, 1024]; Kcat = 1280 + 8
+    pc = ops.patchify_gather(imgs, koff, 1280, Kcat, ps, tok_mod, tok_patch, N, torch.float32)
+    for r in (0, 17, B * N - 1):
+        b, m, p = r // N, int(tok_mod[r]), int(tok_patch[r])
+        py, px = (p // 16) * ps, (p % 16) * ps
+        exp = torch.zeros(Kcat, device=DEV)
+        exp[koff[m]:koff[m] + Ks[m]] = imgs[m][b, :, py:py + ps, px:px + ps].reshape(-1)
+        exp[1280 + m] = 1.0
+        assert torch.equal(pc[r], exp)
