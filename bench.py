@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: pretrain samples/s of the native fusion-token path, ViT-B / 3 modalities / 256x256 tiles.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = Dirichlet mask draw + patch embedding of the kept patches + 12 x (Block_Fusion + Zorro-masked Block) + final
+norm + pooling + 3 decoders + masked MSE/L1 + 3 DINO-style contrastive terms + backward + gradient all-reduce (N > 1) +
+AdamW, on synthetic tiles already resident in HBM (BASELINE.md / SURVEY.md 8d).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+
+
+def build(args, device):
+    from incomplete_multimodal_fusion_amd.pretrain import get_model
+    torch.manual_seed(1234)
+    model = get_model(args.model, input_size=args.input_size, patch_size=16, decoder_dim=256, decoder_depth=2,
+                      decoder_num_heads=8)
+    return model.to(device).train()
+
+
+def synthetic_tiles(B, size, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return {"s1": torch.randn(B, 1, size, size, generator=g).to(device),
+            "s2": torch.randn(B, 3, size, size, generator=g).to(device),
+            "dem": torch.randn(B, 1, size, size, generator=g).to(device)}
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this box's host cores: same model,
+    same step definition (fwd + losses + bwd + AdamW), fp32, a bounded sample of the workload."""
+    from oracle import mmae_oracle as O
+    from incomplete_multimodal_fusion_amd.pretrain import get_model
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    model = get_model(args.model, input_size=args.input_size)
+    p = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("pos_emb") and not k.endswith("beta"))
+         for k, v in model.state_dict().items()}
+    del model
+    B, P = args.cpu_batch, (args.input_size // 16) ** 2
+    N = args.num_encoded_tokens
+    x = synthetic_tiles(B, args.input_size, "cpu", 99)
+    opt = torch.optim.AdamW([t for t in p.values() if t.requires_grad], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    heads = {"tiny": 3}.get(args.model, 8)
+    times = []
+    for it in range(args.cpu_steps + 1):
+        t0 = time.perf_counter()
+        from torch.distributions.dirichlet import Dirichlet
+        d = Dirichlet(torch.ones(3)).sample((1,)); noise = torch.rand(1, 3, P); na = torch.rand(1, 3 * P)
+        mask_all, _, _ = O.masks_from_draws(d, noise, na, N)
+        masks = {dom: mask_all[:, i * P:(i + 1) * P].repeat(B, 1) for i, dom in enumerate(O.DOMAINS)}
+        out, (_, _, loss) = O.train_step_loss(p, x, masks, N, heads, 8, 16)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sum(times) / len(times)
+    return {"value": round(B / t, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%s 3-mod %dx%d, B=%d, N=%d, fp32, %d step(s) after 1 warm-up, %.2f s/step" %
+                      (args.model, args.input_size, args.input_size, B, N, len(times), t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="base")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--input-size", dest="input_size", type=int, default=256)
+    ap.add_argument("--num-encoded-tokens", dest="num_encoded_tokens", type=int, default=384)
+    ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 autocast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
+    ap.add_argument("--bucket-mb", type=int, default=128)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from incomplete_multimodal_fusion_amd import dp, ops
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    distributed = dp.init_distributed()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model = build(args, device)
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    lr = 1e-4 * args.batch * world / 256                                  # pretrain_mmae.py:334-335
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
+    reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
+    step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer)
+    x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)
+    torch.manual_seed(4321 + rank)
+
+    prof = ops.KernelTimer("mmae_mha_fwd")
+    for _ in range(args.warmup):
+        losses = step(x)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(x)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(losses["loss"])
+    assert loss_val == loss_val, "non-finite loss"
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = args.batch * world * args.steps / dt
+        avg_ms, n_launch, flops = prof.summary()
+        # roofline of the fused attention kernel: mask-aware algorithmic FLOPs per launch
+        # 4 * dh * h * sum_b (sum_m N_m^2 + P * S)   (SURVEY.md 8d), accumulated on the device per launch
+        ach = flops / n_launch / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        out = {
+            "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-%s (D768/L12/h8x64) 3-modality (s1+s2+dem) %dx%d tiles, patch 16, N=%d of %d tokens "
+                                   "kept (Dirichlet alpha=1 masks per step), decoders 256/2/8, MSE+L1+0.3*DINO, fwd+bwd+AdamW"
+                                   % (args.model, args.input_size, args.input_size, args.num_encoded_tokens,
+                                      3 * (args.input_size // 16) ** 2),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "trainable_params": n_params, "loss": round(loss_val, 4)},
+            "roofline": {"kernel": "mha_fwd_kernel<bf16,64>" if not args.fp32 else "mha_fwd_kernel<f32,64>",
+                         "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

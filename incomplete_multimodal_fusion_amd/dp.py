@@ -1,0 +1,122 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce over RCCL (xGMI) overlapped with backward.
+
+Replaces the reference's torch DistributedDataParallel wrapper (pretraining/pretrain_mmae.py:343,
+find_unused_parameters=True) and its env:// NCCL bring-up (pretraining/utils/dist.py:62-93).  The only collective on
+the hot path is the gradient all-reduce; samples are independent.
+
+Design for MI355X: few LARGE buckets (default 128 MiB: xGMI is point-to-point, 7 links per GPU, so per-collective
+latency is paid per bucket while bandwidth is per link), filled in reverse registration order = the order backward
+produces gradients, launched from post-accumulate-grad hooks as soon as a bucket is complete so that the transfer runs on
+RCCL's stream underneath the remaining backward kernels.  Parameters that never receive a gradient (the reference needs
+find_unused_parameters for 7 of them) are detected on the first step and then excluded statically -- no graph walk.
+"""
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> bool:
+    """env:// rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (utils/dist.py:62-93).  Returns True when a
+    process group with world_size > 1 is active."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, init_method="env://")
+        dist.barrier()
+    return True
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "expected")
+
+    def __init__(self):
+        self.params, self.offsets = [], []
+        self.flat = None
+        self.pending = 0
+        self.expected = 0
+        self.work = None
+
+
+class GradAllReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
+                 average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.average = average
+        self.buckets: List[_Bucket] = []
+        self._where = {}
+        self._unused = set()
+        self._first = True
+        cur, cur_bytes = _Bucket(), 0
+        for p in reversed(self.params):                     # gradients arrive roughly in reverse registration order
+            nbytes = p.numel() * 4
+            if cur.params and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = _Bucket(), 0
+            cur.offsets.append(cur_bytes // 4)
+            cur.params.append(p)
+            cur_bytes += nbytes
+        if cur.params:
+            self.buckets.append(cur)
+        for bi, b in enumerate(self.buckets):
+            n = b.offsets[-1] + b.params[-1].numel()
+            b.flat = torch.zeros(n, dtype=torch.float32, device=b.params[0].device)
+            for p, off in zip(b.params, b.offsets):
+                self._where[p] = (bi, off)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    # -- per step -----------------------------------------------------------------------------------------------------
+    def prepare(self):
+        for b in self.buckets:
+            b.work = None
+            b.pending = sum(1 for p in b.params if p not in self._unused)
+            b.expected = b.pending
+
+    def _launch(self, b: _Bucket):
+        if self.world > 1:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b.work = True
+
+    def _on_grad(self, p: torch.nn.Parameter):
+        bi, off = self._where[p]
+        b = self.buckets[bi]
+        view = b.flat[off:off + p.numel()].view_as(p)
+        view.copy_(p.grad)
+        p.grad = view                                        # the optimizer reads the reduced bucket in place
+        b.pending -= 1
+        if b.pending == 0 and b.work is None:
+            self._launch(b)
+
+    def finish(self):
+        """Launch what backward could not complete (buckets holding never-used parameters on the first step), wait for
+        every transfer on the current stream, average."""
+        for b in self.buckets:
+            if b.work is None:
+                for p, off in zip(b.params, b.offsets):
+                    if p.grad is None or p.grad.data_ptr() != b.flat[off:off + 1].data_ptr():
+                        b.flat[off:off + p.numel()].zero_()
+                        if self._first:
+                            self._unused.add(p)
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is not True and b.work is not None:
+                b.work.wait()
+            if self.average and self.world > 1:
+                b.flat.mul_(1.0 / self.world)
+        self._first = False
+
+    def unused_parameters(self):
+        return list(self._unused)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

@@ -22,6 +22,37 @@ def _rowmat(t, cols_needed):
     return t, t.stride(0)
 
 
+# ------------------------------------------------------------------------------------------------ kernel timing hook
+class KernelTimer:
+    """HIP-event timing of one C-ABI entry point on the stream it is launched on (bench.py's roofline leg)."""
+
+    def __init__(self, name: str):
+        self.name, self.pairs, self.flops = name, [], None
+
+    def bracket(self):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.append((a, b))
+        return a, b
+
+    def add_flops(self, f: torch.Tensor):
+        self.flops = f if self.flops is None else self.flops + f
+
+    def summary(self):
+        torch.cuda.synchronize()
+        if not self.pairs:
+            return 0.0, 0, 0.0
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return sum(ms) / len(ms), len(ms), float(self.flops.item()) if self.flops is not None else 0.0
+
+
+_TIMER = None
+
+
+def set_kernel_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
 # ------------------------------------------------------------------------------------------------ segments
 class Segments:
     """Device-side segment descriptors for the masked attention: int32 (B, nseg) start rows and lengths."""
@@ -66,12 +97,21 @@ class _MHA(torch.autograd.Function):
         out = torch.empty(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
         lse = torch.empty(H, qt.shape[0], dtype=torch.float32, device=qt.device)
         es = qt.element_size()
+        timed = _TIMER is not None and _TIMER.name == "mmae_mha_fwd" and same
+        if timed:
+            ql, kl = qseg.length.long(), kseg.length.long()
+            pairs = (ql[:, :-1] * kl[:, :-1]).sum() + (ql[:, -1] * kl.sum(1)).sum()     # mask-aware (q, k) pairs
+            _TIMER.add_flops(pairs.double() * (4.0 * dh * H))
+            ev0, ev1 = _TIMER.bracket()
+            ev0.record()
         call("mmae_mha_fwd", dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
              ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(lse),
              qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), qt.shape[0],
              ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length), qseg.max_rows, scale, empty_mode,
              stream())
+        if timed:
+            ev1.record()
         ctx.save_for_backward(qt, kv, out, lse)
         ctx.cfg = (qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same)
         return out

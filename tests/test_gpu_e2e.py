@@ -7,6 +7,22 @@ from oracle import mmae_oracle as O
 from tests.test_cabi_symbols import build_model
 from tests.test_gpu_kernels import DEV, close
 
+
+def grad_close(a, b, tol, autocast, what):
+    """fp32: max-abs error relative to max|ref|.  bf16: gradients of the L1 head are sign functions of bf16-rounded
+    residuals, so single elements legitimately flip; use relative L2 + cosine instead."""
+    if not autocast:
+        return close(a, b, tol, what)
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    assert not torch.isnan(a).any(), what
+    nb = float(b.norm())
+    if nb < 1e-12:
+        assert float(a.norm()) < 1e-6, what
+        return
+    rel = float((a - b).norm()) / nb
+    cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+    assert rel <= 0.2 and cos >= 0.98, "%s: rel L2 %.3e cos %.5f" % (what, rel, cos)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -54,7 +70,7 @@ def test_e2e_golden(g_e2e, case, mode):
     for n in gnames:
         assert params[n].grad is not None, "no grad for " + n
         ref = c["grad/" + n]
-        close(params[n].grad, ref, tol * (10 if autocast else 2), "grad " + n)
+        grad_close(params[n].grad, ref, tol * 2, autocast, "grad " + n)
     for n, p in params.items():          # the 7 parameters that never receive a gradient in the reference
         if p.requires_grad and n not in gnames:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
@@ -104,7 +120,8 @@ def test_e2e_vs_oracle_multitile(mode):
         if ref is None:
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
             continue
-        err = float((prm.grad.double().cpu() - ref.double()).abs().max()); sc = float(ref.abs().max())
-        if err > tol * (10 if autocast else 2) * max(sc, 1e-6):
-            bad.append((n, err, sc))
+        try:
+            grad_close(prm.grad, ref, tol * 2, autocast, "grad " + n)
+        except AssertionError as e:
+            bad.append(str(e))
     assert not bad, bad[:8]

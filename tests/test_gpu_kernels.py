@@ -45,7 +45,9 @@ def check_param_grads(mod, c, tol, prefix="gw."):
     for n, p in mod.named_parameters():
         key = prefix + n
         if key in c:
-            assert p.grad is not None, n
+            if p.grad is None:      # never reached by the graph: the reference reports an all-zero gradient
+                assert float(c[key].abs().max()) == 0.0, n
+                continue
             close(p.grad, c[key], tol, "grad " + n)
 
 
