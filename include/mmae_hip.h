@@ -64,12 +64,12 @@ int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, const float*
                     void* y, const float* gamma1, const float* beta1, float eps1, const float* gamma2,
                     const float* beta2, float eps2, float* stats, void* stream);
 /* gx = LN-backward(gy) + gx_up (optional); written as fp32 (gx) and/or dtype_delta (gdelta).  Column sums
- * dgamma1/2, dbeta1/2 (fp32, D) via workspace ws of mmae_add_ln_bwd_ws_floats(rows, D) floats. */
+ * dgamma1/2, dbeta1/2 (fp32, D; += when accumulate != 0) via workspace ws of mmae_add_ln_bwd_ws_floats(rows, D) floats. */
 int mmae_add_ln_bwd_ws_floats(long rows, int D);
 int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy,
                     const float* gx_up, const float* gamma1, const float* beta1, const float* gamma2,
                     const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1, float* dgamma2,
-                    float* dbeta2, float* ws, void* stream);
+                    float* dbeta2, float* ws, int accumulate, void* stream);
 
 /* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j], exact erf GELU ---------------- */
 int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream);

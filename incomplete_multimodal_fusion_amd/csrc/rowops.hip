@@ -198,14 +198,34 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
     }
 }
 
-__global__ void colsum_finalize_kernel(const float* ws, int nblk, int D, float* o0, float* o1, float* o2, float* o3) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+// out_q[col] (+)= sum_b ws[b][q][col].  grid (ceil(D/64), nq); 1024 threads = 16 row groups x 64 columns (coalesced 256 B
+// per group), 4 independent loads in flight per thread.
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ ws, int nblk, int D, float* o0,
+                                                               float* o1, float* o2, float* o3, int accumulate) {
+    __shared__ float red[1024];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
     const int qn = blockIdx.y;
     float* out = qn == 0 ? o0 : qn == 1 ? o1 : qn == 2 ? o2 : o3;
-    if (col >= D || !out) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[((long)b * 4 + qn) * D + col];
-    out[col] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < D && out) {
+        const float* base = ws + (long)qn * D + col;
+        const long stride = 4L * D;
+        int b = rg;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += base[(long)b * stride]; s1 += base[(long)(b + 16) * stride];
+            s2 += base[(long)(b + 32) * stride]; s3 += base[(long)(b + 48) * stride];
+        }
+        for (; b < nblk; b += 16) s0 += base[(long)b * stride];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && col < D && out) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g * 64 + c];
+        out[col] = accumulate ? out[col] + s : s;
+    }
 }
 
 template <typename TD, typename TY, bool DOUBLE>
@@ -260,24 +280,24 @@ extern "C" int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, c
 }
 
 extern "C" int mmae_add_ln_bwd_ws_floats(long rows, int D) {
-    long nblk = (rows + 3) / 4; if (nblk > 512) nblk = 512; if (nblk < 1) nblk = 1;
+    long nblk = (rows + 3) / 4; if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
     return (int)(nblk * 4 * D);
 }
 
 extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy,
                                const float* gx_up, const float* gamma1, const float* beta1, const float* gamma2,
                                const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1,
-                               float* dgamma2, float* dbeta2, float* ws, void* stream) {
+                               float* dgamma2, float* dbeta2, float* ws, int accumulate, void* stream) {
     if (!ok_dtype(dtype_delta) || !ok_dtype(dtype_y) || rows < 0 || D <= 0 || (D % 4) || D > 1024) return MMAE_ERR_ARG;
     if (!x_new || !gy || !gamma1 || !stats || !ws) return MMAE_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    long nblk = (rows + 3) / 4; if (nblk > 512) nblk = 512; if (nblk < 1) nblk = 1;
+    long nblk = (rows + 3) / 4; if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
     AddLnBwd p{x_new, gy, gx_up, gamma1, beta1, gamma2, stats, gx, gdelta, ws, rows, D};
     const bool dbl = gamma2 != nullptr;
     int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(D, 256), dbl ? 4 : 2), dim3(256), 0, st, ws, (int)nblk, D,
-                       dgamma1, dbeta1, dgamma2, dbeta2);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
+                       dgamma1, dbeta1, dgamma2, dbeta2, accumulate);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

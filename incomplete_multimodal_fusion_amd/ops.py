@@ -234,9 +234,14 @@ class _PartsAddLN(torch.autograd.Function):
         gdelta = torch.empty(dmeta[0], dtype=dmeta[1], device=dev) if dmeta is not None else None
         ddt = dt(dmeta[1]) if dmeta is not None else _lib.F32
         dbl = g2 is not None
-        acc = [None, None, None, None]
+        acc = [torch.empty(D, dtype=torch.float32, device=dev),
+               torch.empty(D, dtype=torch.float32, device=dev) if has_b1 else None,
+               torch.empty(D, dtype=torch.float32, device=dev) if dbl else None,
+               torch.empty(D, dtype=torch.float32, device=dev) if (dbl and has_b2) else None]
+        ws = torch.empty(_lib.lib().mmae_add_ln_bwd_ws_floats(max(rows), D), dtype=torch.float32, device=dev)
         gxs = []
         r0 = 0
+        first = True
         for i, (xn, n, off) in enumerate(zip(ln_in, rows, delta_off)):
             up = ups.pop(0) if off >= 0 else None
             need_gx = ctx.needs_input_grad[6 + i]
@@ -244,21 +249,16 @@ class _PartsAddLN(torch.autograd.Function):
                 gxs.append(None)
                 continue
             gx = torch.empty_like(xn) if need_gx else None
-            part = [torch.empty(D, dtype=torch.float32, device=dev),
-                    torch.empty(D, dtype=torch.float32, device=dev) if has_b1 else None,
-                    torch.empty(D, dtype=torch.float32, device=dev) if dbl else None,
-                    torch.empty(D, dtype=torch.float32, device=dev) if (dbl and has_b2) else None]
-            ws = torch.empty(_lib.lib().mmae_add_ln_bwd_ws_floats(n, D), dtype=torch.float32, device=dev)
             gd = ctypes.c_void_p(gdelta.data_ptr() + off * D * gdelta.element_size()) if off >= 0 else None
             call("mmae_add_ln_bwd", ddt, dt(out_dtype), n, D, ptr(xn),
                  ctypes.c_void_p(gy.data_ptr() + r0 * D * gy.element_size()), ptr(_c(up)) if up is not None else None,
-                 ptr(g1), ptr(b1), ptr(g2), ctypes.c_void_p(stats.data_ptr() + r0 * 16), ptr(gx), gd, ptr(part[0]),
-                 ptr(part[1]), ptr(part[2]), ptr(part[3]), ptr(ws), stream())
-            for k in range(4):
-                if part[k] is not None:
-                    acc[k] = part[k] if acc[k] is None else acc[k] + part[k]
+                 ptr(g1), ptr(b1), ptr(g2), ctypes.c_void_p(stats.data_ptr() + r0 * 16), ptr(gx), gd, ptr(acc[0]),
+                 ptr(acc[1]), ptr(acc[2]), ptr(acc[3]), ptr(ws), 0 if first else 1, stream())
+            first = False
             gxs.append(gx)
             r0 += n
+        if first:
+            acc = [None if a is None else torch.zeros_like(a) for a in acc]
         return (gdelta, acc[0], acc[1], acc[2], acc[3], None, *gxs)
 
 

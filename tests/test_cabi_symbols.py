@@ -20,6 +20,7 @@ def test_header_symbols_exported():
     assert _lib.lib().mmae_abi_version() == 1
     # pure host helpers (no GPU needed)
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(1000, 768) == 250 * 4 * 768
+    assert _lib.lib().mmae_add_ln_bwd_ws_floats(40960, 768) == 1024 * 4 * 768
     off = (ctypes.c_long * 15)()
     total = _lib.lib().mmae_descriptor_layout(2, 3, 16, 24, ctypes.cast(off, ctypes.c_void_p))
     assert total == off[14] and off[13] + 4 == off[14] and off[6] - off[5] == 2 * 24
