@@ -103,3 +103,20 @@ def test_factory_presets_and_signatures():
     assert m.blocks[0].mlp[1].weight.shape == (2 * int(192 * 8 / 3), 192)
     with pytest.raises(AssertionError):
         mc.pretrain_multimae_tiny(ia, None, num_fusion_tokens=8)     # must equal s1.num_patches (reference :87)
+
+
+def test_install_as_multimae_resolves_driver_imports():
+    """The reference driver's import lines (pretrain_mmae.py:35-39) must bind the native modules after aliasing."""
+    import subprocess, sys
+    code = (
+        "import incomplete_multimodal_fusion_amd as n; n.install_as_multimae()\n"
+        "from multimae.multimae_crossattn import pretrain_multimae_base, pretrain_multimae_tiny\n"
+        "from multimae.zorro_utils import TokenTypes as T\n"
+        "from multimae.criterion import MaskedL1Loss, MaskedMSELoss, vicreg, HardNegtive_loss, DINOLoss, byol_loss_func, dino_loss_func\n"
+        "from multimae.input_adapters import PatchedInputAdapter, FusionInputAdapter\n"
+        "from multimae.output_adapters_simple import SpatialOutputAdapter\n"
+        "assert pretrain_multimae_base.__module__.startswith('incomplete_multimodal_fusion_amd')\n"
+        "assert [t.value for t in T] == [0, 1, 2, 3]\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
