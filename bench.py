@@ -84,10 +84,10 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="base")
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--input-size", dest="input_size", type=int, default=256)
     ap.add_argument("--num-encoded-tokens", dest="num_encoded_tokens", type=int, default=384)
     ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 autocast")
@@ -95,7 +95,9 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=2)
     ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=128)
-    ap.add_argument("--tunable", type=int, default=0, help="1: let torch TunableOp pick the hipBLASLt/rocBLAS solution per GEMM shape during warm-up")
+    ap.add_argument("--tunable", type=int, default=1, help="1: torch TunableOp picks the hipBLASLt/rocBLAS solution per GEMM "
+                    "shape (pre-tuned table in incomplete_multimodal_fusion_amd/tuned/, unseen shapes are tuned during warm-up)")
+    ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -110,10 +112,19 @@ def main():
     device = torch.device("cuda", local)
 
     if args.tunable:
+        import shutil
+        import tempfile
         import torch.cuda.tunable as tun
-        tun.enable(True); tun.tuning_enable(True)
-        tun.set_max_tuning_duration(20); tun.set_max_tuning_iterations(20)
-        tun.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_rank%d.csv" % rank))
+        table = os.path.join(ROOT, "incomplete_multimodal_fusion_amd", "tuned", "tunableop_gfx950.csv")
+        work = args.tune_out or os.path.join(tempfile.gettempdir(), "mmae_tunableop_rank%d.csv" % rank)
+        if os.path.isfile(table) and os.path.abspath(table) != os.path.abspath(work):
+            shutil.copyfile(table, work)                       # never write into the tracked table implicitly
+        tun.enable(True)
+        tun.tuning_enable(world == 1)                          # N > 1 runs the same per-GPU shapes: table only
+        tun.set_max_tuning_duration(30); tun.set_max_tuning_iterations(30)
+        tun.set_filename(work)
+        if hasattr(tun, "write_file_on_exit"):
+            tun.write_file_on_exit(bool(args.tune_out))
     model = build(args, device)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     lr = 1e-4 * args.batch * world / 256                                  # pretrain_mmae.py:334-335
