@@ -45,6 +45,9 @@ int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
                  const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                  int empty_mode, void* stream);
 
+/* test hook: 1 routes bf16 through the generic dtype-templated kernels instead of the bf16 fast path (mha_bf16.hip). */
+int mmae_mha_set_generic_bf16(int on);
+
 /* ---- modality attention of Block_Fusion (DSI-MM/zorro_utils.py:252-256 on MM/multimae_crossattn.py:454-462) ---------
  * For each of the B*P (sample, patch) rows: the fusion query (row of q) attends `ns` = M+1 key/value rows of kv
  * (kv[row] = [K (inner) | V (inner)]) named by slot_row (B*P, ns).  Rows < shared_base are token rows, each used by

@@ -28,22 +28,7 @@
 #include "common.hpp"
 #include "mmae_hip.h"
 
-#define MAXSEG 8
-
-struct MhaDesc {
-    const void* q; const void* k; const void* v;
-    void* o;                 // fwd: out; bwd: forward output O (read)
-    const void* dout;        // bwd
-    void* dq; void* dk; void* dv;
-    float* lse;              // (H, q_rows_total)
-    float* delta;            // (H, q_rows_total)
-    long q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
-    const int* q_start; const int* q_len; const int* k_start; const int* k_len;   // (B, nseg) each
-    long stat_stride;        // q_rows_total
-    int B, H, nseg, max_tiles;
-    float scale;
-    int empty_mode;
-};
+#include "mha_common.hpp"
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef f32x4 type; };
@@ -109,36 +94,6 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ src, long row0,
             for (int e = 0; e < 8; ++e) TR[(dc * 8 + e) * VP + r] = v[e];
         }
     }
-}
-
-struct TileSel { int seg, t0, n; };
-
-// XCD-aware block -> (sample, head, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md,
-// dispatch section), so L % 8 names the XCD group of linear block L.  All tiles of one (sample, head) pair are put on the
-// same group: they stream the same K/V (or Q/dO) rows, which then stay in that XCD's 4 MiB L2 instead of being fetched
-// from HBM once per XCD.  Speed only -- correctness does not depend on the placement.
-struct BlockSel { int b, h, t; };
-__device__ __forceinline__ BlockSel decode_block(int L, int max_tiles, int B, int H) {
-    const int xcd = L & 7, slot = L >> 3;
-    const int g = (slot / max_tiles) * 8 + xcd;         // (sample, head) pair index
-    BlockSel r;
-    r.t = slot % max_tiles;
-    r.b = g / H;
-    r.h = g % H;
-    if (g >= B * H) r.b = -1;
-    return r;
-}
-static inline int xcd_grid(int B, int H, int max_tiles) { return ((B * H + 7) / 8) * 8 * max_tiles; }
-// Which (segment, 64-row tile) does linear tile index `t` of this sample denote?  seg = -1: none (block exits).
-__device__ __forceinline__ TileSel select_tile(const int* len, int nseg, int t) {
-    TileSel r; r.seg = -1; r.t0 = 0; r.n = 0;
-    for (int s = 0; s < nseg; ++s) {
-        const int L = len[s];
-        const int nt = (L + 63) >> 6;
-        if (t < nt) { r.seg = s; r.t0 = t * 64; r.n = min(64, L - t * 64); return r; }
-        t -= nt;
-    }
-    return r;
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
@@ -480,6 +435,10 @@ template <typename T, int DH> static int launch_bwd(MhaDesc d, int max_q_tiles, 
     return MMAE_OK;
 }
 
+// test hook: 1 = run bf16 through the generic (dtype-templated) kernels instead of the bf16 fast path
+static int g_use_generic_bf16 = 0;
+extern "C" int mmae_mha_set_generic_bf16(int on) { g_use_generic_bf16 = on; return 0; }
+
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int check_common(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
@@ -508,7 +467,7 @@ extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, con
     d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_tiles = max_q_rows / 64 + nseg;
     d.scale = scale; d.empty_mode = empty_mode;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MMAE_BF16) return head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st);
+    if (dtype == MMAE_BF16) return g_use_generic_bf16 ? (head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st)) : mha_bf16_fwd(d, head_dim, st);
     return head_dim == 64 ? launch_fwd<float, 64>(d, st) : launch_fwd<float, 32>(d, st);
 }
 
@@ -535,6 +494,6 @@ extern "C" int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, con
     d.scale = scale; d.empty_mode = empty_mode;
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MMAE_BF16) return head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st);
+    if (dtype == MMAE_BF16) return g_use_generic_bf16 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, st);
     return head_dim == 64 ? launch_bwd<float, 64>(d, mq, mk, st) : launch_bwd<float, 32>(d, mq, mk, st);
 }

@@ -1,0 +1,55 @@
+// Shared declarations of the masked-attention kernels (mha.hip: generic fp32/bf16; mha_bf16.hip: bf16 fast path).
+#pragma once
+#include "common.hpp"
+
+#define MAXSEG 8
+
+struct MhaDesc {
+    const void* q; const void* k; const void* v;
+    void* o;                 // fwd: out; bwd: forward output O (read)
+    const void* dout;        // bwd
+    void* dq; void* dk; void* dv;
+    float* lse;              // (H, q_rows_total)
+    float* delta;            // (H, q_rows_total)
+    long q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
+    const int* q_start; const int* q_len; const int* k_start; const int* k_len;   // (B, nseg) each
+    long stat_stride;        // q_rows_total
+    int B, H, nseg, max_tiles;
+    float scale;
+    int empty_mode;
+};
+
+struct TileSel { int seg, t0, n; };
+
+// XCD-aware block -> (sample, head, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md,
+// dispatch section), so L % 8 names the XCD group of linear block L.  All tiles of one (sample, head) pair are put on the
+// same group: they stream the same K/V (or Q/dO) rows, which then stay in that XCD's 4 MiB L2 instead of being fetched
+// from HBM once per XCD.  Speed only -- correctness does not depend on the placement.
+struct BlockSel { int b, h, t; };
+__device__ __forceinline__ BlockSel decode_block(int L, int max_tiles, int B, int H) {
+    const int xcd = L & 7, slot = L >> 3;
+    const int g = (slot / max_tiles) * 8 + xcd;         // (sample, head) pair index
+    BlockSel r;
+    r.t = slot % max_tiles;
+    r.b = g / H;
+    r.h = g % H;
+    if (g >= B * H) r.b = -1;
+    return r;
+}
+static inline int xcd_grid(int B, int H, int max_tiles) { return ((B * H + 7) / 8) * 8 * max_tiles; }
+// Which (segment, 64-row tile) does linear tile index `t` of this sample denote?  seg = -1: none (block exits).
+__device__ __forceinline__ TileSel select_tile(const int* len, int nseg, int t) {
+    TileSel r; r.seg = -1; r.t0 = 0; r.n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int L = len[s];
+        const int nt = (L + 63) >> 6;
+        if (t < nt) { r.seg = s; r.t0 = t * 64; r.n = min(64, L - t * 64); return r; }
+        t -= nt;
+    }
+    return r;
+}
+
+
+// bf16 fast path (mha_bf16.hip)
+int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st);
+int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, hipStream_t st);

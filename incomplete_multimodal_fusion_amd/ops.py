@@ -96,6 +96,8 @@ class _MHA(torch.autograd.Function):
         assert qt.dtype == kv.dtype
         out = torch.empty(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
         lse = torch.empty(H, qt.shape[0], dtype=torch.float32, device=qt.device)
+        assert kseg.max_rows // 64 + kseg.nseg <= 80 and qseg.max_rows // 64 + qseg.nseg <= 80, \
+            "at most ~4.8k rows per sample in one attention call"
         es = qt.element_size()
         timed = _TIMER is not None and _TIMER.name == "mmae_mha_fwd" and same
         if timed:
