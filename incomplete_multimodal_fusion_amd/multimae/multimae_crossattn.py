@@ -281,7 +281,7 @@ class MultiMAE(nn.Module):
             # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
             (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
                                            out_dtype=T)                                     # (BN+BP, D)
-            qkv = linear(z, torch.cat([blk.attn.to_q.weight, blk.attn.to_kv.weight], dim=0))
+            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight])
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
             o = linear(a, blk.attn.to_out.weight)
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,

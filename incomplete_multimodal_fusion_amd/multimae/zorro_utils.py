@@ -44,9 +44,9 @@ def wcast(w: torch.Tensor, dtype) -> torch.Tensor:
 
 
 def linear(x, weight, bias=None):
-    """Dense projection on hipBLASLt via torch (the 'plain library GEMM' of the design)."""
-    with torch.autocast("cuda", enabled=False):
-        return F.linear(x, wcast(weight, x.dtype), None if bias is None else wcast(bias, x.dtype))
+    """Dense projection: library GEMMs (hipBLASLt/rocBLAS through torch) for y and dx, split-K batched GEMM with an fp32
+    sum for the weight gradient (ops._Linear).  `weight` may be a list of master weights to be row-concatenated."""
+    return ops.linear(x, weight, bias)
 
 
 def segments_from_mask(mask: torch.Tensor, B: int):
@@ -199,8 +199,7 @@ class Attention(nn.Module):      # zorro_utils.py:152-194
                 segments = segments_from_mask(attn_mask, B)
         qseg, kseg = segments
         if context is None:
-            wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0)
-            qkv = linear(y, wqkv)
+            qkv = linear(y, [self.to_q.weight, self.to_kv.weight])
             a = ops._MHA.apply(qkv, None, 0, H * dh, 2 * H * dh, H, dh, qseg, kseg, self.scale, empty_mode)
         else:
             q = linear(y, self.to_q.weight)

@@ -85,6 +85,72 @@ class Segments:
         return Segments(st, ln, n)
 
 
+# ------------------------------------------------------------------------------------------------ dense projections
+def _split_k(rows: int, n_out: int, n_in: int) -> int:
+    """Split factor for the weight-gradient GEMM dW = g^T x (n_out x n_in output, contraction over `rows`).
+    The output has few 256x256 tiles (6..48 at ViT-B) while the contraction is 65k..165k long, so a single GEMM leaves
+    most of the 256 CUs idle (measured 290-830 TFLOP/s).  Splitting the contraction into S batched GEMMs + an fp32 sum
+    fills the chip: largest power of two with tiles * S <= 256, S <= 32 (tools/probes/wgrad_splitk_probe.py: 1.3-3.2x)."""
+    tiles = ((n_out + 255) // 256) * ((n_in + 255) // 256)
+    s = 1
+    while s < 32 and tiles * s * 2 <= 256 and rows % (s * 2) == 0 and rows // (s * 2) >= 2048:
+        s *= 2
+    return s
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ cat(ws)^T (+ bias) on hipBLASLt/rocBLAS through torch.  `ws` are the fp32 master weights (cast to the
+    compute dtype here); the weight gradient comes back in fp32 straight from a split-K batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, bias, *ws):
+        T = x.dtype
+        w = ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+        w = w if w.dtype == T else w.to(T)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(x, w, None if bias is None else (bias if bias.dtype == T else bias.to(T)))
+        ctx.save_for_backward(x, w)
+        ctx.meta = ([wi.shape[0] for wi in ws], [wi.dtype for wi in ws], bias is not None and bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        sizes, wdt, bdt = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        with torch.autocast("cuda", enabled=False):
+            gx = torch.mm(g2, w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            gws = [None] * len(sizes)
+            if any(ctx.needs_input_grad[2:]):
+                rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
+                S = _split_k(rows, n_out, n_in)
+                if S > 1:
+                    gw = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in)) \
+                        .sum(0, dtype=torch.float32)
+                else:
+                    gw = torch.mm(g2.t(), x2).float()
+                off = 0
+                for i, n in enumerate(sizes):
+                    if ctx.needs_input_grad[2 + i]:
+                        gi = gw[off:off + n]
+                        gws[i] = gi if gi.dtype == wdt[i] else gi.to(wdt[i])
+                    off += n
+            gb = None
+            if bdt is not False and ctx.needs_input_grad[1]:
+                gb = g2.sum(0, dtype=torch.float32)
+                gb = gb if gb.dtype == bdt else gb.to(bdt)
+        return (gx, gb, *gws)
+
+
+def linear(x, weight, bias=None):
+    """weight: one (N, K) master weight or a list of them (row-concatenated, e.g. [to_q.weight, to_kv.weight])."""
+    ws = weight if isinstance(weight, (list, tuple)) else (weight,)
+    return _Linear.apply(x, bias, *ws)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 class _MHA(torch.autograd.Function):
     @staticmethod
