@@ -57,7 +57,9 @@ int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, int inner, c
                      void* stream);
 int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
                      const void* kv, long kv_stride, const int* slot_row, const void* dout, long do_stride, void* dq,
-                     long dq_stride, void* dkv, long dkv_stride, int shared_base, float scale, void* stream);
+                     long dq_stride, void* dkv, long dkv_stride, int shared_base, float scale, float* ws, void* stream);
+/* ws: fp32 workspace of mmae_modattn_bwd_nsplit(B) * P * 2*inner floats (partial sums of the shared rows). */
+int mmae_modattn_bwd_nsplit(int B);
 
 /* ---- fused residual add + LayerNorm / double LayerNorm (DSI-MM/zorro_utils.py:103-110, :176, :124, :238-239, :255-257;
  *      decoder nn.LayerNorm eps 1e-6, MM/output_adapters_simple.py:75; final norm MM/multimae_crossattn.py:472) ------

@@ -8,9 +8,10 @@
 // kv[(token rows | P mask-embedding rows), 2*I] and `slot_row[(b,p), s]` names the row each slot reads; the
 // (B,P,M+1,D) tensor is never materialised.  HBM-bound: one wave per (b,p), 16 B per lane, heads = groups of DH/8 lanes.
 //
-// Backward: one block per patch p, its 4 waves stride over the samples; token rows are written once each (every token
-// row belongs to exactly one slot), the shared mask-embedding row `shared_base + p` is accumulated in registers over the
-// samples and stored once -> deterministic, no atomics.
+// Backward: grid (patch p, sample group); a block's 4 waves stride over the samples of its group; token rows are written
+// once each (every token row belongs to exactly one slot); the shared mask-embedding row `shared_base + p` is accumulated
+// in registers over the samples, reduced over the 4 waves in LDS into an fp32 partial slab per sample group, and the
+// slabs are summed in fixed order by a second small kernel -> deterministic, no atomics.
 #include "common.hpp"
 #include "mmae_hip.h"
 
@@ -52,6 +53,8 @@ struct ModAttn {
     long rows;            // B*P
     int I, ns, P, B, shared_base;
     float scale;
+    float* ws;            // backward: (nsplit, P, 2*I) fp32 partial sums of the shared rows
+    int nsplit;
 };
 
 template <typename T, int DH>
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void modattn_bwd_kernel(ModAttn p) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2*I]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = blockIdx.x;                                     // patch
+    const int sp = blockIdx.y;                                     // sample group: b = sp*4 + wave, step 4*nsplit
     const T* kv = reinterpret_cast<const T*>(p.kv);
     T* dkv = reinterpret_cast<T*>(p.dkv);
     float accK[NCH][8], accV[NCH][8];
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void modattn_bwd_kernel(ModAttn p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { accK[ch][j] = 0.f; accV[ch][j] = 0.f; }
 
-    for (int b = wave; b < p.B; b += 4) {
+    for (int b = sp * 4 + wave; b < p.B; b += 4 * p.nsplit) {
         const long row = (long)b * p.P + pp;
         const T* q = reinterpret_cast<const T*>(p.q) + row * p.q_stride;
         const T* dout = reinterpret_cast<const T*>(p.dout) + row * p.do_stride;
@@ -200,9 +204,22 @@ __global__ __launch_bounds__(256) void modattn_bwd_kernel(ModAttn p) {
         }
     }
     __syncthreads();
-    T* drow = dkv + (long)(p.shared_base + pp) * p.dkv_stride;
-    for (int c = threadIdx.x; c < I2; c += 256)
-        drow[c] = from_f<T>(red[c] + red[I2 + c] + red[2 * I2 + c] + red[3 * I2 + c]);
+    float* wrow = p.ws + ((long)sp * p.P + pp) * I2;
+    for (int c = threadIdx.x; c < I2; c += 256) wrow[c] = red[c] + red[I2 + c] + red[2 * I2 + c] + red[3 * I2 + c];
+}
+
+// shared (mask-embedding) rows: sum the per-sample-group partial slabs in a fixed order -> deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void modattn_bwd_finish_kernel(ModAttn p) {
+    const int I2 = 2 * p.I;
+    const long n = (long)p.P * I2;
+    T* dkv = reinterpret_cast<T*>(p.dkv);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < p.nsplit; ++k) s += p.ws[(long)k * n + i];
+        const long pp = i / I2, c = i % I2;
+        dkv[(p.shared_base + pp) * p.dkv_stride + c] = from_f<T>(s);
+    }
 }
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -237,20 +254,24 @@ extern "C" int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, i
     return MMAE_OK;
 }
 
+// sample groups per patch in the backward (each block's 4 waves stride over the samples of its group)
+extern "C" int mmae_modattn_bwd_nsplit(int B) { int n = B / 32; return n < 1 ? 1 : (n > 16 ? 16 : n); }
+
 extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, int inner, const void* q, long q_stride,
                                 const void* kv, long kv_stride, const int* slot_row, const void* dout, long do_stride,
                                 void* dq, long dq_stride, void* dkv, long dkv_stride, int shared_base, float scale,
-                                void* stream) {
+                                float* ws, void* stream) {
     int rc = ma_check(dtype, head_dim, B, P, ns, inner, q_stride, kv_stride, do_stride);
     if (rc) return rc;
     if ((dq_stride % 8) || (dkv_stride % 8) || shared_base < 0) return MMAE_ERR_ARG;
-    if (!q || !kv || !slot_row || !dout || !dq || !dkv || !al16(q) || !al16(kv) || !al16(dout) || !al16(dq) || !al16(dkv)) return MMAE_ERR_ARG;
+    if (!q || !kv || !slot_row || !dout || !dq || !dkv || !ws || !al16(q) || !al16(kv) || !al16(dout) || !al16(dq) || !al16(dkv)) return MMAE_ERR_ARG;
     ModAttn p{};
+    p.ws = ws; p.nsplit = mmae_modattn_bwd_nsplit(B);
     p.q = q; p.kv = kv; p.slot_row = slot_row; p.dout = dout; p.dq = dq; p.dkv = dkv;
     p.q_stride = q_stride; p.kv_stride = kv_stride; p.do_stride = do_stride; p.dq_stride = dq_stride; p.dkv_stride = dkv_stride;
     p.rows = (long)B * P; p.I = inner; p.ns = ns; p.P = P; p.B = B; p.shared_base = shared_base; p.scale = scale;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(P), blk(256);
+    dim3 grid(P, p.nsplit), blk(256);
     const size_t lds = (size_t)4 * 2 * inner * sizeof(float);
     const bool two = inner > 512;
 #define GO(T, DHV, NCHV) hipLaunchKernelGGL((modattn_bwd_kernel<T, DHV, NCHV>), grid, blk, lds, st, p)
@@ -260,6 +281,10 @@ extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, i
         if (head_dim == 64) { if (two) GO(float, 64, 2); else GO(float, 64, 1); } else { if (two) GO(float, 32, 2); else GO(float, 32, 1); }
     }
 #undef GO
+    MMAE_CHECK_LAUNCH();
+    const long n = (long)P * 2 * inner;
+    if (dtype == MMAE_BF16) hipLaunchKernelGGL((modattn_bwd_finish_kernel<bf16>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((modattn_bwd_finish_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
