@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=2)
     ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=128)
+    ap.add_argument("--side-wgrad", type=int, default=0, help="1: weight-gradient GEMMs on a side stream (measured: no gain)")
     ap.add_argument("--tunable", type=int, default=1, help="1: torch TunableOp picks the hipBLASLt/rocBLAS solution per GEMM "
                     "shape (pre-tuned table in incomplete_multimodal_fusion_amd/tuned/, unseen shapes are tuned during warm-up)")
     ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
@@ -130,7 +131,8 @@ def main():
     lr = 1e-4 * args.batch * world / 256                                  # pretrain_mmae.py:334-335
     opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
     reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
-    step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer)
+    step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer,
+                        side_stream_wgrad=bool(args.side_wgrad))
     x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)
     torch.manual_seed(4321 + rank)
 

@@ -47,6 +47,8 @@ int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
 
 /* test hook: 1 routes bf16 through the generic dtype-templated kernels instead of the bf16 fast path (mha_bf16.hip). */
 int mmae_mha_set_generic_bf16(int on);
+/* tuning hook: kernel variant of the bf16 fast path (0 = default; see mha_bf16.hip). */
+int mmae_mha_set_variant(int v);
 
 /* ---- modality attention of Block_Fusion (DSI-MM/zorro_utils.py:252-256 on MM/multimae_crossattn.py:454-462) ---------
  * For each of the B*P (sample, patch) rows: the fusion query (row of q) attends `ns` = M+1 key/value rows of kv

@@ -22,6 +22,27 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Cross-lane reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with VALU-only lane swaps
+// (v_permlane16_swap / v_permlane32_swap) instead of __shfl_xor, which lowers to ds_bpermute through the LDS crossbar.
+// permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b; with a == b == v the two results hold, for every lane,
+// v of its own half and v of the other half.  permlane16_swap does the same for odd/even 16-lane rows.
+__device__ __forceinline__ float rows_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 // 8 k-slots of the column (col0 + lane&15) of a row-major LDS image: slots j<4 -> rows row0 + 4g + j,
 // j>=4 -> rows row0 + 16 + 4g + (j-4)   (g = lane>>4).  Matches acc_pair_to_frag()'s slot order.
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* img, int pitch, int row0, int col0, int lane) {
@@ -46,43 +67,98 @@ __device__ __forceinline__ void st4(bf16* p, const f32x4& v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-template <int DH> struct Geo {
-    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH + 8, CPR = DH / 8, NCH = 64 * CPR / 256;
+template <int DH, int NT = 256> struct Geo {
+    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH + 8, CPR = DH / 8, NCH = 64 * CPR / NT;
 };
 
 // global -> registers: this thread's chunks of a [<=64 rows][DH] tile (rows >= n zero-filled)
-template <int DH>
+template <int DH, int NT = 256>
 __device__ __forceinline__ void tile_load(const bf16* src, long row0, long stride, int col0, int n, int tid,
-                                          bf16x8 (&reg)[Geo<DH>::NCH]) {
+                                          bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
 #pragma unroll
-    for (int i = 0; i < Geo<DH>::NCH; ++i) {
-        const int c = tid + 256 * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
+    for (int i = 0; i < Geo<DH, NT>::NCH; ++i) {
+        const int c = tid + NT * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
         reg[i] = r < n ? ld8(src + (row0 + r) * stride + col0 + dc * 8) : z8();
     }
 }
-template <int DH>
-__device__ __forceinline__ void tile_store(bf16* img, int tid, const bf16x8 (&reg)[Geo<DH>::NCH]) {
+template <int DH, int NT = 256>
+__device__ __forceinline__ void tile_store(bf16* img, int tid, const bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
 #pragma unroll
-    for (int i = 0; i < Geo<DH>::NCH; ++i) {
-        const int c = tid + 256 * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
+    for (int i = 0; i < Geo<DH, NT>::NCH; ++i) {
+        const int c = tid + NT * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
         *reinterpret_cast<bf16x8*>(img + r * Geo<DH>::KP + dc * 8) = reg[i];
     }
 }
 
+// Segment table of one sample, fetched in ONE parallel round trip: lane s (< nseg) holds entry s of the four arrays;
+// get() broadcasts a (wave-uniform) entry with a lane read.  Replaces ~5 dependent global reads per block prologue.
+struct SegTab {
+    int qlen, qst, klen, kst;
+    __device__ __forceinline__ void load(const MhaDesc& p, int b, int lane) {
+        const int i = b * p.nseg + (lane < p.nseg ? lane : 0);
+        qlen = p.q_len[i]; qst = p.q_start[i]; klen = p.k_len[i]; kst = p.k_start[i];
+    }
+    __device__ __forceinline__ int ql(int s) const { return __shfl(qlen, s); }
+    __device__ __forceinline__ int qs(int s) const { return __shfl(qst, s); }
+    __device__ __forceinline__ int kl(int s) const { return __shfl(klen, s); }
+    __device__ __forceinline__ int ks(int s) const { return __shfl(kst, s); }
+};
+// (segment, 64-row tile) of linear tile index t over the lengths len(s); seg = -1: none
+template <int BM = 64, typename F> __device__ __forceinline__ TileSel pick_tile(F len, int nseg, int t) {
+    TileSel r; r.seg = -1; r.t0 = 0; r.n = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int L = len(s);
+        const int nt = (L + BM - 1) / BM;
+        if (r.seg < 0 && t < nt) { r.seg = s; r.t0 = t * BM; r.n = min(BM, L - t * BM); }
+        t -= nt;
+    }
+    return r;
+}
+
 // key tiles a query tile sweeps: filled by thread 0, read by everyone after a barrier
 struct KeyPlan { int begin, end; bool uniform; };
-__device__ __forceinline__ KeyPlan key_plan(int seg, int nseg, const int* klen, int empty_mode) {
+__device__ __forceinline__ KeyPlan key_plan(int seg, int nseg, int klen_seg, int empty_mode) {
     KeyPlan k; k.begin = 0; k.end = 0; k.uniform = false;
     if (seg == nseg - 1) { k.begin = 0; k.end = nseg; }
-    else if (klen[seg] > 0) { k.begin = seg; k.end = seg + 1; }
+    else if (klen_seg > 0) { k.begin = seg; k.end = seg + 1; }
     else if (empty_mode == 0) { k.begin = 0; k.end = nseg; k.uniform = true; }
     return k;
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(256) void mha_bf16_fwd_kernel(MhaDesc p) {
-    typedef Geo<DH> G;
+// Per-thread staging geometry: chunk i of this thread covers row (tid + NT*i) / CPR, 8 columns at ((tid + NT*i) % CPR)*8.
+// The element offset inside a tile is loop invariant; only the tile's first row (a wave-uniform scalar) changes.
+template <int DH, int NT> struct StageIdx {
+    long goff[Geo<DH, NT>::NCH];     // row * stride + col  (elements), relative to the tile's first row
+    int row[Geo<DH, NT>::NCH];
+    int loff[Geo<DH, NT>::NCH];      // LDS element offset
+    __device__ __forceinline__ void init(int tid, long stride, int col0) {
+#pragma unroll
+        for (int i = 0; i < Geo<DH, NT>::NCH; ++i) {
+            const int c = tid + NT * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
+            row[i] = r; goff[i] = (long)r * stride + col0 + dc * 8; loff[i] = r * Geo<DH>::KP + dc * 8;
+        }
+    }
+};
+template <int DH, int NT>
+__device__ __forceinline__ void tile_load2(const bf16* base, const StageIdx<DH, NT>& ix, int n,
+                                           bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
+#pragma unroll
+    for (int i = 0; i < Geo<DH, NT>::NCH; ++i) reg[i] = ix.row[i] < n ? ld8(base + ix.goff[i]) : z8();
+}
+template <int DH, int NT>
+__device__ __forceinline__ void tile_store2(bf16* img, const StageIdx<DH, NT>& ix, const bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
+#pragma unroll
+    for (int i = 0; i < Geo<DH, NT>::NCH; ++i) *reinterpret_cast<bf16x8*>(img + ix.loff[i]) = reg[i];
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// __launch_bounds__(.., 2): at most 256 registers per lane, so the compiler selects the VGPR form of the MFMAs -- with the
+// default budget it parks accumulators in AGPRs and pays ~80 v_accvgpr_read/write per tile around the softmax.
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
+    typedef Geo<DH, NW * 64> G;
+    constexpr int NT = NW * 64, BM = NW * 16;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * G::KP];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * G::KP];
     __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
@@ -91,17 +167,18 @@ __global__ __launch_bounds__(256) void mha_bf16_fwd_kernel(MhaDesc p) {
     const BlockSel bs = decode_block(blockIdx.x, p.max_tiles, p.B, p.H);
     if (bs.b < 0) return;
     const int b = bs.b, h = bs.h;
-    const int* qlen = p.q_len + b * p.nseg; const int* qst = p.q_start + b * p.nseg;
-    const int* klen = p.k_len + b * p.nseg; const int* kst = p.k_start + b * p.nseg;
-    const TileSel ts = select_tile(qlen, p.nseg, bs.t);
+    SegTab st; st.load(p, b, lane);
+    const TileSel ts = pick_tile<BM>([&](int s) { return st.ql(s); }, p.nseg, bs.t);
     if (ts.seg < 0) return;
-    const long qrow0 = (long)qst[ts.seg] + ts.t0;
-    const KeyPlan kp = key_plan(ts.seg, p.nseg, klen, p.empty_mode);
-    if (tid == 0) {
+    const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
+    const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
+    if (wave == 0) {                                           // whole wave takes part in the lane broadcasts
         int n = 0;
-        for (int s = kp.begin; s < kp.end; ++s)
-            for (int j0 = 0; j0 < klen[s] && n < MAXT; j0 += 64) { tl_row[n] = kst[s] + j0; tl_n[n] = min(64, klen[s] - j0); ++n; }
-        tl_cnt = n;
+        for (int s = kp.begin; s < kp.end; ++s) {
+            const int L = st.kl(s), r0 = st.ks(s);
+            for (int j0 = 0; j0 < L && n < MAXT; j0 += 64) { if (lane == 0) { tl_row[n] = r0 + j0; tl_n[n] = min(64, L - j0); } ++n; }
+        }
+        if (lane == 0) tl_cnt = n;
     }
     const int myq = wave * 16 + lr;
     const bool qvalid = myq < ts.n;
@@ -112,8 +189,7 @@ __global__ __launch_bounds__(256) void mha_bf16_fwd_kernel(MhaDesc p) {
         for (int ks = 0; ks < G::KS; ++ks) qf[ks] = qvalid ? ld8(qp + 32 * ks) : z8();
     }
     __syncthreads();
-    const int ntile = tl_cnt;
-    const float c = kp.uniform ? 0.f : p.scale * LOG2E;       // scores enter the exp2 domain through one fma
+    const int ntile = uni(tl_cnt);
     float m = -INFINITY, l = 0.f;                             // m is kept in the scaled (log2) domain
     f32x4 oacc[G::DT];
 #pragma unroll
@@ -121,67 +197,98 @@ __global__ __launch_bounds__(256) void mha_bf16_fwd_kernel(MhaDesc p) {
 
     const bf16* kg = reinterpret_cast<const bf16*>(p.k);
     const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    StageIdx<DH, NT> ixk, ixv;
+    ixk.init(tid, p.k_stride, h * DH);
+    ixv.init(tid, p.v_stride, h * DH);
+    // LDS fragment addresses (loop invariant)
+    const bf16* kfrag = Ks + lr * G::KP + 8 * g;
     bf16x8 kreg[G::NCH], vreg[G::NCH];
     if (ntile > 0) {
-        tile_load<DH>(kg, tl_row[0], p.k_stride, h * DH, tl_n[0], tid, kreg);
-        tile_load<DH>(vg, tl_row[0], p.v_stride, h * DH, tl_n[0], tid, vreg);
+        const long r0 = uni(tl_row[0]); const int n0 = uni(tl_n[0]);
+        tile_load2<DH, NT>(kg + r0 * p.k_stride, ixk, n0, kreg);
+        tile_load2<DH, NT>(vg + r0 * p.v_stride, ixv, n0, vreg);
     }
-    for (int t = 0; t < ntile; ++t) {
-        __syncthreads();
-        tile_store<DH>(Ks, tid, kreg);
-        tile_store<DH>(Vs, tid, vreg);
-        __syncthreads();
-        const int kn = tl_n[t];
-        if (t + 1 < ntile) {
-            tile_load<DH>(kg, tl_row[t + 1], p.k_stride, h * DH, tl_n[t + 1], tid, kreg);
-            tile_load<DH>(vg, tl_row[t + 1], p.v_stride, h * DH, tl_n[t + 1], tid, vreg);
-        }
-        f32x4 s[4];
+    if (!kp.uniform) {
+        const float c = p.scale * LOG2E;                      // scores enter the exp2 domain through one fma
+        for (int t = 0; t < ntile; ++t) {
+            __syncthreads();
+            tile_store2<DH, NT>(Ks, ixk, kreg);
+            tile_store2<DH, NT>(Vs, ixv, vreg);
+            __syncthreads();
+            const int kn = uni(tl_n[t]);
+            if (t + 1 < ntile) {
+                const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
+                tile_load2<DH, NT>(kg + r1 * p.k_stride, ixk, n1, kreg);
+                tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
+            }
+            f32x4 s[4];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t4 = 0; t4 < 4; ++t4) {
+                s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks)
-                s[t4] = mma16(ld8(Ks + (16 * t4 + lr) * G::KP + 32 * ks + 8 * g), qf[ks], s[t4]);
-        }
-        if (kn < 64) {                                        // ragged last tile of a segment (block-uniform branch)
+                for (int ks = 0; ks < G::KS; ++ks)
+                    s[t4] = mma16(ld8(kfrag + 16 * t4 * G::KP + 32 * ks), qf[ks], s[t4]);
+            }
+            if (kn < 64) {                                    // ragged last tile of a segment: scalar branch
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t4 + 4 * g + r >= kn) s[t4][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+            for (int t4 = 1; t4 < 4; ++t4) mx = fmaxf(mx, fmaxf(fmaxf(s[t4][0], s[t4][1]), fmaxf(s[t4][2], s[t4][3])));
+            mx = rows_max(mx);
+            const float m_new = fmaxf(m, mx * c);             // c > 0: max(c*s) = c*max(s); every tile has a valid key
+            const float alpha = fast_exp2(m - m_new);
+            float rs = 0.f;
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * t4 + 4 * g + r >= kn) s[t4][r] = -INFINITY;
-        }
-        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(__builtin_fmaf(s[t4][r], c, -m_new));   // -inf -> 0
+                    s[t4][r] = e;
+                    rs += e;
+                }
+            rs = rows_sum(rs);
+            l = l * alpha + rs;
+            m = m_new;
 #pragma unroll
-        for (int t4 = 1; t4 < 4; ++t4) mx = fmaxf(mx, fmaxf(fmaxf(s[t4][0], s[t4][1]), fmaxf(s[t4][2], s[t4][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // c >= 0: max(c*s) = c*max(s); uniform rows (c == 0): all valid scores are 0 (mx may be -inf only if kn == 0)
-        const float m_new = fmaxf(m, kp.uniform ? 0.f : mx * c);
-        const float alpha = fast_exp2(m - m_new);
-        float rs = 0.f;
+            for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const bf16x8 pb = pack8(s[2 * ks2], s[2 * ks2 + 1]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // masked keys hold -inf: fma(-inf, c>0, x) = -inf -> 0; for uniform rows mask explicitly
-                float e = fast_exp2(__builtin_fmaf(s[t4][r], c, -m_new));
-                if (kp.uniform) e = (16 * t4 + 4 * g + r < kn) ? 1.f : 0.f;
-                s[t4][r] = e;
-                rs += e;
+                for (int dt = 0; dt < G::DT; ++dt)
+                    oacc[dt] = mma16(tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane), pb, oacc[dt]);
             }
-        rs += __shfl_xor(rs, 16);
-        rs += __shfl_xor(rs, 32);
-        l = l * alpha + rs;
-        m = m_new;
+        }
+    } else {
+        // fully masked rows (finite masked_fill in the reference): uniform attention over every key -> column sums of V
+        m = 0.f;
+        for (int t = 0; t < ntile; ++t) {
+            __syncthreads();
+            tile_store2<DH, NT>(Vs, ixv, vreg);
+            __syncthreads();
+            const int kn = uni(tl_n[t]);
+            if (t + 1 < ntile) {
+                const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
+                tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
+            }
+            l += (float)kn;
+            f32x4 one4[4];
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            const bf16x8 pb = pack8(s[2 * ks2], s[2 * ks2 + 1]);
+                for (int r = 0; r < 4; ++r) one4[t4][r] = (16 * t4 + 4 * g + r < kn) ? 1.f : 0.f;
 #pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
-                oacc[dt] = mma16(tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane), pb, oacc[dt]);
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const bf16x8 pb = pack8(one4[2 * ks2], one4[2 * ks2 + 1]);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt)
+                    oacc[dt] = mma16(tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane), pb, oacc[dt]);
+            }
         }
     }
     if (qvalid) {
@@ -194,9 +301,12 @@ __global__ __launch_bounds__(256) void mha_bf16_fwd_kernel(MhaDesc p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+// No per-element masks: rows of a ragged tile beyond its length are ZERO in the LDS images, so a padded key has K = V = 0
+// and contributes K^T dS = 0 to dQ whatever its (finite) dS is.
 template <int DH>
-__global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
+__global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
     typedef Geo<DH> G;
+    constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * G::KP];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * G::KP];
     __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
@@ -205,18 +315,19 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
     const BlockSel bs = decode_block(blockIdx.x, p.max_tiles, p.B, p.H);
     if (bs.b < 0) return;
     const int b = bs.b, h = bs.h;
-    const int* qlen = p.q_len + b * p.nseg; const int* qst = p.q_start + b * p.nseg;
-    const int* klen = p.k_len + b * p.nseg; const int* kst = p.k_start + b * p.nseg;
-    const TileSel ts = select_tile(qlen, p.nseg, bs.t);
+    SegTab st; st.load(p, b, lane);
+    const TileSel ts = pick_tile([&](int s) { return st.ql(s); }, p.nseg, bs.t);
     if (ts.seg < 0) return;
-    const long qrow0 = (long)qst[ts.seg] + ts.t0;
-    const KeyPlan kp = key_plan(ts.seg, p.nseg, klen, p.empty_mode);
-    if (tid == 0) {
+    const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
+    const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
+    if (wave == 0) {
         int n = 0;
         if (!kp.uniform)          // dS == 0 for a uniform (fully masked) row: nothing flows to q
-            for (int s = kp.begin; s < kp.end; ++s)
-                for (int j0 = 0; j0 < klen[s] && n < MAXT; j0 += 64) { tl_row[n] = kst[s] + j0; tl_n[n] = min(64, klen[s] - j0); ++n; }
-        tl_cnt = n;
+            for (int s = kp.begin; s < kp.end; ++s) {
+                const int L = st.kl(s), r0 = st.ks(s);
+                for (int j0 = 0; j0 < L && n < MAXT; j0 += 64) { if (lane == 0) { tl_row[n] = r0 + j0; tl_n[n] = min(64, L - j0); } ++n; }
+            }
+        if (lane == 0) tl_cnt = n;
     }
     const int myq = wave * 16 + lr;
     const bool qvalid = myq < ts.n;
@@ -235,13 +346,11 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
             for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
         }
     }
-    dpart += __shfl_xor(dpart, 16);
-    dpart += __shfl_xor(dpart, 32);
-    const float delta = dpart;
+    const float delta = rows_sum(dpart);
     const float lse2 = (qvalid ? p.lse[(long)h * p.stat_stride + qrow0 + myq] : 0.f) * LOG2E;
     if (qvalid && g == 0) p.delta[(long)h * p.stat_stride + qrow0 + myq] = delta;
     __syncthreads();
-    const int ntile = tl_cnt;
+    const int ntile = uni(tl_cnt);
     const float c = p.scale * LOG2E;
 
     f32x4 dqacc[G::DT];
@@ -249,20 +358,26 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
     for (int dt = 0; dt < G::DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16* kg = reinterpret_cast<const bf16*>(p.k);
     const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    StageIdx<DH, NT> ixk, ixv;
+    ixk.init(tid, p.k_stride, h * DH);
+    ixv.init(tid, p.v_stride, h * DH);
+    const bf16* kfrag = Ks + lr * G::KP + 8 * g;
+    const bf16* vfrag = Vs + lr * G::KP + 8 * g;
     bf16x8 kreg[G::NCH], vreg[G::NCH];
     if (ntile > 0) {
-        tile_load<DH>(kg, tl_row[0], p.k_stride, h * DH, tl_n[0], tid, kreg);
-        tile_load<DH>(vg, tl_row[0], p.v_stride, h * DH, tl_n[0], tid, vreg);
+        const long r0 = uni(tl_row[0]); const int n0 = uni(tl_n[0]);
+        tile_load2<DH, NT>(kg + r0 * p.k_stride, ixk, n0, kreg);
+        tile_load2<DH, NT>(vg + r0 * p.v_stride, ixv, n0, vreg);
     }
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();
-        tile_store<DH>(Ks, tid, kreg);
-        tile_store<DH>(Vs, tid, vreg);
+        tile_store2<DH, NT>(Ks, ixk, kreg);
+        tile_store2<DH, NT>(Vs, ixv, vreg);
         __syncthreads();
-        const int kn = tl_n[t];
         if (t + 1 < ntile) {
-            tile_load<DH>(kg, tl_row[t + 1], p.k_stride, h * DH, tl_n[t + 1], tid, kreg);
-            tile_load<DH>(vg, tl_row[t + 1], p.v_stride, h * DH, tl_n[t + 1], tid, vreg);
+            const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
+            tile_load2<DH, NT>(kg + r1 * p.k_stride, ixk, n1, kreg);
+            tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
         }
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -271,17 +386,16 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
             dp[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s[t4] = mma16(ld8(Ks + (16 * t4 + lr) * G::KP + 32 * ks + 8 * g), qf[ks], s[t4]);
-                dp[t4] = mma16(ld8(Vs + (16 * t4 + lr) * G::KP + 32 * ks + 8 * g), dof[ks], dp[t4]);
+                s[t4] = mma16(ld8(kfrag + 16 * t4 * G::KP + 32 * ks), qf[ks], s[t4]);
+                dp[t4] = mma16(ld8(vfrag + 16 * t4 * G::KP + 32 * ks), dof[ks], dp[t4]);
             }
         }
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float pv = fast_exp2(__builtin_fmaf(s[t4][r], c, -lse2));
-                if (kn < 64 && 16 * t4 + 4 * g + r >= kn) pv = 0.f;
-                s[t4][r] = pv * (dp[t4][r] - delta) * p.scale;       // dS^T
+                const float pv = fast_exp2(__builtin_fmaf(s[t4][r], c, -lse2));
+                s[t4][r] = pv * (dp[t4][r] - delta) * p.scale;       // dS^T (finite also for padded keys)
             }
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -299,35 +413,40 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ backward: dK, dV
+// No per-element masks either: a padded query row has Q = dO = 0 (zero-filled image) and lse = delta = 0, so P is finite
+// and both dO^T P and Q^T dS get exactly 0 from it; a padded key column only pollutes its own (never stored) column.
 template <int DH>
-__global__ __launch_bounds__(256) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
+__global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
     typedef Geo<DH> G;
+    constexpr int NT = 256;
     __shared__ __attribute__((aligned(16))) bf16 Qs[64 * G::KP];
     __shared__ __attribute__((aligned(16))) bf16 dOs[64 * G::KP];
-    __shared__ float lse_s[64], delta_s[64];
+    __shared__ __attribute__((aligned(16))) float lse_s[64];
+    __shared__ __attribute__((aligned(16))) float delta_s[64];
     __shared__ int tl_row[MAXT], tl_n[MAXT], tl_mode[MAXT], tl_cnt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
     const BlockSel bs = decode_block(blockIdx.x, p.max_tiles, p.B, p.H);
     if (bs.b < 0) return;
     const int b = bs.b, h = bs.h;
-    const int* qlen = p.q_len + b * p.nseg; const int* qst = p.q_start + b * p.nseg;
-    const int* klen = p.k_len + b * p.nseg; const int* kst = p.k_start + b * p.nseg;
-    const TileSel ts = select_tile(klen, p.nseg, bs.t);
+    SegTab st; st.load(p, b, lane);
+    const TileSel ts = pick_tile([&](int s) { return st.kl(s); }, p.nseg, bs.t);
     if (ts.seg < 0) return;
-    const long krow0 = (long)kst[ts.seg] + ts.t0;
-    if (tid == 0) {
+    const long krow0 = (long)st.ks(ts.seg) + ts.t0;
+    if (wave == 0) {
         int n = 0;
         for (int sq = 0; sq < p.nseg; ++sq) {
+            const int QL = st.ql(sq), r0 = st.qs(sq), KL = st.kl(sq);
             int mode = 0;                                          // 0 skip, 1 normal, 2 uniform row
             if (sq == p.nseg - 1 || sq == ts.seg) mode = 1;
-            else if (klen[sq] == 0 && p.empty_mode == 0) mode = 2;
+            else if (KL == 0 && p.empty_mode == 0) mode = 2;
             if (mode == 0) continue;
-            for (int q0 = 0; q0 < qlen[sq] && n < MAXT; q0 += 64) {
-                tl_row[n] = qst[sq] + q0; tl_n[n] = min(64, qlen[sq] - q0); tl_mode[n] = mode; ++n;
+            for (int q0 = 0; q0 < QL && n < MAXT; q0 += 64) {
+                if (lane == 0) { tl_row[n] = r0 + q0; tl_n[n] = min(64, QL - q0); tl_mode[n] = mode; }
+                ++n;
             }
         }
-        tl_cnt = n;
+        if (lane == 0) tl_cnt = n;
     }
     const int mykey = wave * 16 + lr;
     const bool kvalid = mykey < ts.n;
@@ -345,30 +464,37 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
-    const int ntile = tl_cnt;
+    const int ntile = uni(tl_cnt);
     const float c = p.scale * LOG2E;
     const bf16* qg = reinterpret_cast<const bf16*>(p.q);
     const bf16* dog = reinterpret_cast<const bf16*>(p.dout);
+    StageIdx<DH, NT> ixq, ixo;
+    ixq.init(tid, p.q_stride, h * DH);
+    ixo.init(tid, p.do_stride, h * DH);
+    const bf16* qfrag = Qs + lr * G::KP + 8 * g;
+    const bf16* dofrag = dOs + lr * G::KP + 8 * g;
+    const float* lse_g = p.lse + (long)h * p.stat_stride;
+    const float* delta_g = p.delta + (long)h * p.stat_stride;
     bf16x8 qreg[G::NCH], doreg[G::NCH];
     float lreg = 0.f, dreg = 0.f;
     auto fetch = [&](int t) {
-        const int row = tl_row[t], n = tl_n[t];
-        tile_load<DH>(qg, row, p.q_stride, h * DH, n, tid, qreg);
-        tile_load<DH>(dog, row, p.do_stride, h * DH, n, tid, doreg);
+        const long row = uni(tl_row[t]); const int n = uni(tl_n[t]);
+        tile_load2<DH, NT>(qg + row * p.q_stride, ixq, n, qreg);
+        tile_load2<DH, NT>(dog + row * p.do_stride, ixo, n, doreg);
         if (tid < 64) {
             const bool v = tid < n;
-            lreg = v ? p.lse[(long)h * p.stat_stride + row + tid] * LOG2E : 0.f;
-            dreg = v ? p.delta[(long)h * p.stat_stride + row + tid] : 0.f;
+            lreg = v ? lse_g[row + tid] * LOG2E : 0.f;
+            dreg = v ? delta_g[row + tid] : 0.f;
         }
     };
     if (ntile > 0) fetch(0);
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();
-        tile_store<DH>(Qs, tid, qreg);
-        tile_store<DH>(dOs, tid, doreg);
+        tile_store2<DH, NT>(Qs, ixq, qreg);
+        tile_store2<DH, NT>(dOs, ixo, doreg);
         if (tid < 64) { lse_s[tid] = lreg; delta_s[tid] = dreg; }
         __syncthreads();
-        const int qn = tl_n[t], mode = tl_mode[t];
+        const int mode = uni(tl_mode[t]);
         if (t + 1 < ntile) fetch(t + 1);
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -377,23 +503,28 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
             dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s[qt] = mma16(ld8(Qs + (16 * qt + lr) * G::KP + 32 * ks + 8 * g), kf[ks], s[qt]);
-                dp[qt] = mma16(ld8(dOs + (16 * qt + lr) * G::KP + 32 * ks + 8 * g), vf[ks], dp[qt]);
+                s[qt] = mma16(ld8(qfrag + 16 * qt * G::KP + 32 * ks), kf[ks], s[qt]);
+                dp[qt] = mma16(ld8(dofrag + 16 * qt * G::KP + 32 * ks), vf[ks], dp[qt]);
             }
         }
+        if (mode == 1) {
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
+            for (int qt = 0; qt < 4; ++qt) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = 16 * qt + 4 * g + r;
-                float pv, ds;
-                if (mode == 2) { pv = fast_exp2(-l4[r]); ds = 0.f; }
-                else { pv = fast_exp2(__builtin_fmaf(s[qt][r], c, -l4[r])); ds = pv * (dp[qt][r] - d4[r]) * p.scale; }
-                const bool valid = kvalid && qi < qn;
-                s[qt][r] = valid ? pv : 0.f;
-                dp[qt][r] = valid ? ds : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = fast_exp2(__builtin_fmaf(s[qt][r], c, -l4[r]));
+                    s[qt][r] = pv;
+                    dp[qt][r] = pv * (dp[qt][r] - d4[r]) * p.scale;
+                }
+            }
+        } else {                                                  // uniform (fully masked) query rows: P = 1/K, dS = 0
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[qt][r] = fast_exp2(-l4[r]); dp[qt][r] = 0.f; }
             }
         }
 #pragma unroll
@@ -416,11 +547,19 @@ __global__ __launch_bounds__(256) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
+static int g_variant = 0;   // tuning hook: 8 = 8 waves (128 query rows) per block in the forward kernel
+extern "C" int mmae_mha_set_variant(int v) { g_variant = v; return 0; }
+
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
-    dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
-    if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_fwd_kernel<64>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((mha_bf16_fwd_kernel<32>), grid, dim3(256), 0, st, d);
+    if (head_dim == 64 && g_variant == 8) {
+        MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
+        hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
+    } else {
+        dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
+        if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 4>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((mha_bf16_fwd_kernel<32, 4>), grid, dim3(256), 0, st, d);
+    }
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

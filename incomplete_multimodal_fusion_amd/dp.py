@@ -87,6 +87,9 @@ class GradAllReducer:
             b.work = True
 
     def _on_grad(self, p: torch.nn.Parameter):
+        if p.grad is not None and p.grad.is_cuda:
+            from . import ops
+            ops.join_wgrad_stream()                          # the gradient may come from the side-stream wgrad GEMM
         bi, off = self._where[p]
         b = self.buckets[bi]
         view = b.flat[off:off + p.numel()].view_as(p)

@@ -104,6 +104,8 @@ class MultiMAE(nn.Module):
         self.per_sample_masks = False      # True: every sample draws / uses its own mask row (packed superset)
         self.fuse_unpatchify_loss = False  # True: preds are PredTokens (fused unpatchify + masked loss)
         self.check_masks = True            # explicit task_masks: verify kept count == num_encoded_tokens (host sync)
+        self.side_stream_wgrad = False     # True: encoder weight-gradient GEMMs overlap the backward chain on a side
+                                           # stream; the trainer must ops.join_wgrad_stream() before reading .grad
 
         self._reset_parameters()
 
@@ -266,27 +268,28 @@ class MultiMAE(nn.Module):
             assert a is b
             return a, a_off, b_off
 
+        sw = self.side_stream_wgrad
         for l in range(self.depth):
             fus, blk = self.fus_blocks[l], self.blocks[l]
             # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) ---------------------------
             dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
             (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
                                               fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
-            kv = linear(z, fus.attn.to_kv.weight)                                           # K/V of every slot source
-            q = linear(z[BN:BN + BP], fus.attn.to_q.weight)                                 # fusion slot queries only
+            kv = linear(z, fus.attn.to_kv.weight, side_wgrad=sw)                                           # K/V of every slot source
+            q = linear(z[BN:BN + BP], fus.attn.to_q.weight, side_wgrad=sw)                                 # fusion slot queries only
             a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
-            o = linear(a, fus.attn.to_out.weight)
+            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw)
             (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
-            f = linear(ops.geglu(linear(y, fus.mlp[1].weight)), fus.mlp[3].weight)          # (BP, D)
+            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw)), fus.mlp[3].weight, side_wgrad=sw)          # (BP, D)
             # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
             (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
                                            out_dtype=T)                                     # (BN+BP, D)
-            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight])
+            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw)
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
-            o = linear(a, blk.attn.to_out.weight)
+            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw)
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
                                            out_dtype=T)
-            f = linear(ops.geglu(linear(y, blk.mlp[1].weight)), blk.mlp[3].weight)          # (BN+BP, D)
+            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw)), blk.mlp[3].weight, side_wgrad=sw)          # (BN+BP, D)
             dm, dm_off, df, df_off = f, 0, f, BN
 
         # ---- final norm (:472) -------------------------------------------------------------------------------------------

@@ -98,25 +98,45 @@ def _split_k(rows: int, n_out: int, n_in: int) -> int:
     return s
 
 
+_WGRAD_STREAMS = {}
+WGRAD_STREAM_PRIORITY = int(__import__('os').environ.get('MMAE_WGRAD_PRIO', '-1'))   # high priority: own HW queue
+WGRAD_SIDE_STREAM = True     # weight-gradient GEMMs of single-use weights run on a side HIP stream (see _Linear.backward)
+
+
+def wgrad_stream(device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _WGRAD_STREAMS.get(dev)
+    if s is None:
+        s = _WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=WGRAD_STREAM_PRIORITY)
+    return s
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for every weight-gradient GEMM issued so far (call before grads are consumed)."""
+    s = _WGRAD_STREAMS.get(torch.cuda.current_device())
+    if s is not None:
+        torch.cuda.current_stream().wait_stream(s)
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ cat(ws)^T (+ bias) on hipBLASLt/rocBLAS through torch.  `ws` are the fp32 master weights (cast to the
     compute dtype here); the weight gradient comes back in fp32 straight from a split-K batched GEMM."""
 
     @staticmethod
-    def forward(ctx, x, bias, *ws):
+    def forward(ctx, x, bias, side, *ws):
         T = x.dtype
         w = ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
         w = w if w.dtype == T else w.to(T)
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(x, w, None if bias is None else (bias if bias.dtype == T else bias.to(T)))
         ctx.save_for_backward(x, w)
-        ctx.meta = ([wi.shape[0] for wi in ws], [wi.dtype for wi in ws], bias is not None and bias.dtype)
+        ctx.meta = ([wi.shape[0] for wi in ws], [wi.dtype for wi in ws], bias is not None and bias.dtype, side)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        sizes, wdt, bdt = ctx.meta
+        sizes, wdt, bdt, side = ctx.meta
         g2 = g.reshape(-1, g.shape[-1])
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
@@ -126,31 +146,54 @@ class _Linear(torch.autograd.Function):
             # 10-30 % faster than the "nn" form at these shapes); transposing the small weight costs ~nothing
             gx = torch.nn.functional.linear(g2, w.t().contiguous()).reshape(x.shape) if ctx.needs_input_grad[0] else None
             gws = [None] * len(sizes)
-            if any(ctx.needs_input_grad[2:]):
+            if any(ctx.needs_input_grad[3:]):
                 rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
                 S = _split_k(rows, n_out, n_in)
-                if S > 1:
-                    gw = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in)) \
-                        .sum(0, dtype=torch.float32)
-                else:
-                    gw = torch.mm(g2.t(), x2).float()
-                off = 0
-                for i, n in enumerate(sizes):
-                    if ctx.needs_input_grad[2 + i]:
-                        gi = gw[off:off + n]
-                        gws[i] = gi if gi.dtype == wdt[i] else gi.to(wdt[i])
-                    off += n
+                # The weight gradient is off the critical path (nothing in this backward pass reads it) and MFMA-bound,
+                # while the kernels that follow on the main stream (GEGLU / LayerNorm / attention backward) are
+                # HBM-bound: issue it on a side stream so the two classes overlap.  Only for weights used once per step
+                # (their .grad is assigned, never accumulated, before join_wgrad_stream()).
+                use_side = side and WGRAD_SIDE_STREAM and g2.is_cuda
+                main = torch.cuda.current_stream() if use_side else None
+                ss = wgrad_stream() if use_side else None
+                if use_side:
+                    ss.wait_stream(main)
+                    g2.record_stream(ss); x2.record_stream(ss)
+                with torch.cuda.stream(ss) if use_side else _NullCtx():
+                    if S > 1:
+                        gw = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in)) \
+                            .sum(0, dtype=torch.float32)
+                    else:
+                        gw = torch.mm(g2.t(), x2).float()
+                    off = 0
+                    for i, n in enumerate(sizes):
+                        if ctx.needs_input_grad[3 + i]:
+                            gi = gw[off:off + n]
+                            gws[i] = gi if gi.dtype == wdt[i] else gi.to(wdt[i])
+                            if use_side:
+                                gws[i].record_stream(main)
+                        off += n
             gb = None
             if bdt is not False and ctx.needs_input_grad[1]:
                 gb = g2.sum(0, dtype=torch.float32)
                 gb = gb if gb.dtype == bdt else gb.to(bdt)
-        return (gx, gb, *gws)
+        return (gx, gb, None, *gws)
 
 
-def linear(x, weight, bias=None):
-    """weight: one (N, K) master weight or a list of them (row-concatenated, e.g. [to_q.weight, to_kv.weight])."""
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def linear(x, weight, bias=None, side_wgrad=False):
+    """weight: one (N, K) master weight or a list of them (row-concatenated, e.g. [to_q.weight, to_kv.weight]).
+    side_wgrad: the weights are used exactly once per step, so their gradient GEMM may run on the side stream; the
+    caller must join_wgrad_stream() before the gradients are read (PretrainStep / GradAllReducer do)."""
     ws = weight if isinstance(weight, (list, tuple)) else (weight,)
-    return _Linear.apply(x, bias, *ws)
+    return _Linear.apply(x, bias, bool(side_wgrad), *ws)
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -10,6 +10,7 @@ from typing import Dict, Iterable, Optional
 
 import torch
 
+from . import ops
 from .multimae import (FusionInputAdapter, MaskedL1Loss, MaskedMSELoss, PatchedInputAdapter, SpatialOutputAdapter,
                        TokenTypes, dino_loss_func)
 from .multimae import multimae_crossattn as mc
@@ -75,13 +76,14 @@ class PretrainStep:
 
     def __init__(self, model, optimizer, num_encoded_tokens: int, in_domains=('s1', 's2', 'dem'), alphas: float = 1.0,
                  sample_tasks_uniformly: bool = False, autocast: bool = True, patch_size: int = 16,
-                 grad_reducer=None):
+                 grad_reducer=None, side_stream_wgrad: bool = False):
         self.model, self.opt = model, optimizer
         self.N, self.in_domains, self.alphas, self.uniform = num_encoded_tokens, tuple(in_domains), alphas, sample_tasks_uniformly
         self.autocast, self.patch = autocast, patch_size
         self.loss_fns = make_loss_fns(tuple(model.output_adapters.keys()), patch_size)
         self.reducer = grad_reducer
         model.fuse_unpatchify_loss = True
+        model.side_stream_wgrad = side_stream_wgrad
 
     def __call__(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None):
         x = {t: v for t, v in tasks_dict.items() if t in self.in_domains}
@@ -93,6 +95,7 @@ class PretrainStep:
         if self.reducer is not None:
             self.reducer.prepare()
         loss.backward()
+        ops.join_wgrad_stream()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()

@@ -125,3 +125,41 @@ def test_e2e_vs_oracle_multitile(mode):
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, bad[:8]
+
+
+def test_side_stream_wgrad_is_race_free_and_bitwise_equal():
+    """Weight-gradient GEMMs on the side stream must give exactly the gradients of the single-stream schedule
+    (every kernel on this path is deterministic), over several repetitions with allocator churn in between."""
+    from incomplete_multimodal_fusion_amd import ops
+    from incomplete_multimodal_fusion_amd.pretrain import get_model, step_losses
+    torch.manual_seed(5)
+    model = get_model("small", input_size=128, decoder_dim=64, decoder_depth=1, decoder_num_heads=2).to(DEV).train()
+    model.depth = 3; model.blocks = model.blocks[:3]; model.fus_blocks = model.fus_blocks[:3]
+    model.fuse_unpatchify_loss = True
+    B, P, N = 64, 64, 96
+    x = {"s1": torch.randn(B, 1, 128, 128, device=DEV), "s2": torch.randn(B, 3, 128, 128, device=DEV),
+         "dem": torch.randn(B, 1, 128, 128, device=DEV)}
+    masks = {}
+    for d, k in (("s1", 40), ("s2", 30), ("dem", 26)):
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1).to(DEV)
+
+    def grads(side):
+        model.side_stream_wgrad = side
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x, task_masks=masks, num_encoded_tokens=N)
+            _, _, loss = step_losses(out, x, masks, 16)
+        loss.backward()
+        ops.join_wgrad_stream()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    ref = grads(False)
+    for rep in range(4):
+        junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]       # churn the caching allocator
+        del junk
+        got = grads(True)
+        assert got.keys() == ref.keys()
+        for n in ref:
+            assert torch.equal(got[n], ref[n]), (rep, n)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the masked attention kernels at the bench workload's shapes (one process, interleaved variants).
+
+    python tools/bench_attn.py [--B 256] [--variants 0,1,...]      variant = value passed to mmae_mha_set_variant()
+"""
+import argparse, sys, os, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from incomplete_multimodal_fusion_amd import _lib, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=256)
+ap.add_argument("--H", type=int, default=8)
+ap.add_argument("--dh", type=int, default=64)
+ap.add_argument("--variants", default="0")
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")
+a = ap.parse_args()
+dev = "cuda"
+B, H, dh, P = a.B, a.H, a.dh, 256
+nm = [int(x) for x in a.split.split(",")]
+N = sum(nm); S = N + P; I = H * dh
+lens = torch.tensor([nm + [P]] * B, dtype=torch.int32)
+st = torch.zeros_like(lens)
+for b in range(B):
+    off = 0
+    for s_ in range(len(nm)):
+        st[b, s_] = b * N + off; off += nm[s_]
+    st[b, len(nm)] = B * N + b * P
+seg = ops.Segments(st.to(dev), lens.to(dev), S)
+torch.manual_seed(0)
+qkv = torch.randn(B * S, 3 * I, device=dev).to(torch.bfloat16).requires_grad_()
+g = torch.randn(B * S, I, device=dev).to(torch.bfloat16)
+pairs = sum(n * n for n in nm) + P * S
+flops_fwd = 4.0 * dh * H * pairs * B
+lib = _lib.lib()
+has_var = hasattr(lib, "mmae_mha_set_variant")
+
+def run(variant):
+    if has_var:
+        lib.mmae_mha_set_variant(variant)
+    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    for _ in range(a.iters):
+        out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+    e[1].record()
+    for _ in range(a.iters):
+        qkv.grad = None
+        out.backward(g, retain_graph=True)
+    e[2].record()
+    torch.cuda.synchronize()
+    return e[0].elapsed_time(e[1]) / a.iters * 1e3, e[1].elapsed_time(e[2]) / a.iters * 1e3
+
+variants = [int(v) for v in a.variants.split(",")]
+res = {v: [] for v in variants}
+for r in range(a.rounds):
+    for v in variants:
+        res[v].append(run(v))
+for v in variants:
+    f = sorted(x[0] for x in res[v]); bw = sorted(x[1] for x in res[v])
+    fm, bm = f[len(f) // 2], bw[len(bw) // 2]
+    print("variant %d: fwd %7.1f us (%6.1f TF/s mask-aware)   bwd(dq+dkdv) %7.1f us (%6.1f TF/s at 3.5x fwd flops)   [min fwd %.1f bwd %.1f]"
+          % (v, fm, flops_fwd / fm / 1e6, bm, 3.5 * flops_fwd / bm / 1e6, f[0], bw[0]), flush=True)
