@@ -108,8 +108,8 @@ def main():
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)   # (% only matters for the
+    torch.cuda.set_device(local)                                                          #  single-GPU gloo rehearsal)
     device = torch.device("cuda", local)
 
     if args.tunable:

@@ -25,9 +25,9 @@ def init_distributed(backend: Optional[str] = None) -> bool:
         return False
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            backend = os.environ.get("MMAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, init_method="env://")
         dist.barrier()
     return True
