@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=2)
     ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=128)
+    ap.add_argument("--engine", type=int, default=1, help="1: flat-buffer fused AdamW + bf16 shadow weights (csrc/optim.hip); "
+                    "0: torch.optim.AdamW(fused=True) on the fp32 parameters")
     ap.add_argument("--side-wgrad", type=int, default=0, help="1: weight-gradient GEMMs on a side stream (measured: no gain)")
     ap.add_argument("--tunable", type=int, default=1, help="1: torch TunableOp picks the hipBLASLt/rocBLAS solution per GEMM "
                     "shape (pre-tuned table in incomplete_multimodal_fusion_amd/tuned/, unseen shapes are tuned during warm-up)")
@@ -129,8 +131,14 @@ def main():
     model = build(args, device)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     lr = 1e-4 * args.batch * world / 256                                  # pretrain_mmae.py:334-335
-    opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
-    reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
+    if args.engine:
+        from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+        opt = FlatAdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05,
+                        exclude=model.never_used_parameters())
+        reducer = dp.GradAllReducer(None, bucket_bytes=args.bucket_mb << 20, engine=opt) if distributed else None
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
+        reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
     step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer,
                         side_stream_wgrad=bool(args.side_wgrad))
     x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)

@@ -125,6 +125,15 @@ int mmae_hardneg_loss_fwd(int B, int D, const float* out_1, const float* out_2, 
 int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const float* out_2, float tau_plus, float beta,
                           float temperature, float* ws, const float* gloss, float* g1, float* g2, void* stream);
 
+/* ---- fused AdamW over flat buffers (PT/utils/optim_factory.py:136-179 + PT/utils/native_scaler.py:20-40, :49-62) ------
+ * torch.optim.AdamW update rule on n fp32 elements (n % 4 == 0, 16-byte aligned); g is multiplied by grad_scale first
+ * (loss-scale / averaging); `shadow_bf16` (optional) receives bf16(p) -- the weights the next forward's GEMMs read. */
+int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);
+/* L2 norm of a flat fp32 gradient buffer (deterministic two-stage sum); partial_ws: 2048 floats. */
+int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, float* out_norm, void* stream);
+
 /* ---- mask bookkeeping (MM/multimae_crossattn.py:233-272 with injected draws; :402-447, :454-462, :489-493) ---------- */
 int mmae_masks_from_draws(int R, int M, int P, int N, const float* dirichlet, const float* noise,
                           const float* noise_all, long long* mask_all, long long* ids_keep, long long* ids_restore,

@@ -46,7 +46,13 @@ class _Bucket:
 
 class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
-                 average: bool = True):
+                 average: bool = True, engine=None):
+        """engine: an engine.FlatAdamW whose flat gradient buffer is all-reduced in place (buckets = contiguous ranges of
+        it, no staging copies); without it the reducer owns its bucket buffers."""
+        self.engine = engine
+        if engine is not None:
+            self._init_flat(engine, bucket_bytes, group, average)
+            return
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -73,6 +79,33 @@ class GradAllReducer:
                 self._where[p] = (bi, off)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
+    def _init_flat(self, engine, bucket_bytes, group, average):
+        self.params = list(engine.params)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.average = average
+        self.buckets, self._where, self._unused, self._first = [], {}, set(), True
+        # flat order == registration order; gradients arrive roughly in reverse, so buckets are cut from the end
+        ranges, cur, hi, end = [], [], engine.n, engine.n
+        for p in reversed(self.params):
+            off = engine.offsets[id(p)]
+            if cur and (hi - off) * 4 > bucket_bytes:
+                ranges.append((end, hi, cur))                # [end, hi) holds the parameters collected so far
+                cur, hi = [], end
+            cur.append(p)
+            end = off
+        if cur:
+            ranges.append((end, hi, cur))
+        for bi, (lo, hi, ps) in enumerate(ranges):
+            b = _Bucket()
+            b.flat = engine.grads[lo:hi]
+            b.params = ps
+            b.offsets = [engine.offsets[id(p)] - lo for p in ps]
+            self.buckets.append(b)
+            for p, off in zip(b.params, b.offsets):
+                self._where[p] = (bi, off)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
     # -- per step -----------------------------------------------------------------------------------------------------
     def prepare(self):
         for b in self.buckets:
@@ -93,8 +126,9 @@ class GradAllReducer:
         bi, off = self._where[p]
         b = self.buckets[bi]
         view = b.flat[off:off + p.numel()].view_as(p)
-        view.copy_(p.grad)
-        p.grad = view                                        # the optimizer reads the reduced bucket in place
+        if p.grad.data_ptr() != view.data_ptr():             # (engine: Linear gradients are already written in place)
+            view.copy_(p.grad)
+            p.grad = view                                    # the optimizer reads the reduced bucket in place
         b.pending -= 1
         if b.pending == 0 and b.work is None:
             self._launch(b)

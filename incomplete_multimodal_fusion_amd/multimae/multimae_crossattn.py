@@ -126,6 +126,16 @@ class MultiMAE(nn.Module):
             elif isinstance(m, nn.Conv2d) and '.proj' in name:
                 nn.init.xavier_uniform_(m.weight.data.view([m.weight.shape[0], -1]))
 
+    def never_used_parameters(self):
+        """Trainable parameters the training graph never reaches (the reference needs DDP's find_unused_parameters for
+        them): the pooled `return_tokens` (their loss path is detached, criterion.py:333) and every
+        decoder's task embeddings of OTHER tasks (output_adapters_simple.py:172-174 reads self.task only)."""
+        out = [self.return_tokens]
+        for task, ad in (self.output_adapters or {}).items():
+            if getattr(ad, "task_embeddings", None) is not None:
+                out += [p for k, p in ad.task_embeddings.items() if k != ad.task]
+        return out
+
     @torch.jit.ignore
     def no_weight_decay(self):
         no_wd = {'global_tokens'}
@@ -247,7 +257,7 @@ class MultiMAE(nn.Module):
         wcat = torch.cat([self.input_adapters[d].proj.weight.reshape(D, -1) for d in doms] +
                          [torch.stack([self.input_adapters[d].proj.bias for d in doms], dim=1),
                           pcat.new_zeros(D, Kcat - onehot - M, dtype=torch.float32)], dim=1)
-        tok = linear(pcat, wcat)                                                   # (B*N, D), bias included
+        tok = linear(pcat, wcat, once=True)                                                   # (B*N, D), bias included
         pe_table = torch.cat([interp_posemb(self.input_adapters[d].pos_emb, nh, nw) for d in doms], dim=0)
         if pe_table.requires_grad:
             xm = pe_table.index_select(0, desc.tok_pe.long())
@@ -275,21 +285,21 @@ class MultiMAE(nn.Module):
             dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
             (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
                                               fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
-            kv = linear(z, fus.attn.to_kv.weight, side_wgrad=sw)                                           # K/V of every slot source
-            q = linear(z[BN:BN + BP], fus.attn.to_q.weight, side_wgrad=sw)                                 # fusion slot queries only
+            kv = linear(z, fus.attn.to_kv.weight, side_wgrad=sw, once=True)                                           # K/V of every slot source
+            q = linear(z[BN:BN + BP], fus.attn.to_q.weight, side_wgrad=sw, once=True)                                 # fusion slot queries only
             a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
-            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw)
+            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
             (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
-            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw)), fus.mlp[3].weight, side_wgrad=sw)          # (BP, D)
+            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw, once=True)), fus.mlp[3].weight, side_wgrad=sw, once=True)          # (BP, D)
             # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
             (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
                                            out_dtype=T)                                     # (BN+BP, D)
-            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw)
+            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
-            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw)
+            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
                                            out_dtype=T)
-            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw)), blk.mlp[3].weight, side_wgrad=sw)          # (BN+BP, D)
+            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw, once=True)), blk.mlp[3].weight, side_wgrad=sw, once=True)          # (BN+BP, D)
             dm, dm_off, df, df_off = f, 0, f, BN
 
         # ---- final norm (:472) -------------------------------------------------------------------------------------------
@@ -302,7 +312,7 @@ class MultiMAE(nn.Module):
         # ---- attention pooling into the return tokens (:475-497) ---------------------------------------------------------
         ap = self.attn_pool
         R = self.max_return_tokens
-        kvp = linear(tokens_T, ap.to_kv.weight)                                             # (BN+BP, 2I), context un-normalised
+        kvp = linear(tokens_T, ap.to_kv.weight, once=True)                                             # (BN+BP, 2I), context un-normalised
         rq = linear(ops.layernorm(self.return_tokens[0].contiguous(), ap.norm.gamma, out_dtype=T), ap.to_q.weight)
         a = ops.mha_cross(rq.repeat(B, 1), kvp, Hh, dh, desc.pool_q, desc.enc_seg, ap.scale, empty_mode=0)
         pooled = linear(a, ap.to_out.weight).float()                                        # (B*R, D)
@@ -321,7 +331,7 @@ class MultiMAE(nn.Module):
         for d, adapter in self.output_adapters.items():
             rows = enc_rows.float() if d in fp32_output_adapters else enc_rows               # fp32 adapters (:518-527)
             with torch.autocast("cuda", enabled=False) if d in fp32_output_adapters else _nullctx():
-                tk = adapter.forward_tokens(rows, B, P, dec_seg)
+                tk = adapter.forward_tokens(rows, B, P, dec_seg, once=True)
             C = adapter.num_channels
             preds[d] = PredTokens(tk, B, C, H, W, adapter.P_H) if self.fuse_unpatchify_loss else \
                 ops.unpatchify(tk, B, C, H, W, adapter.P_H)

@@ -68,15 +68,15 @@ class Attention(nn.Module):      # multimae_utils.py:158-182 (fused qkv with bia
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward_rows(self, y, B, N, seg=None):
+    def forward_rows(self, y, B, N, seg=None, once=False):
         """y (B*N, C) already normalised, compute dtype -> (B*N, C)."""
         C = y.shape[1]
         H = self.num_heads
-        qkv = linear(y, self.qkv.weight, self.qkv.bias)            # columns [q | k | v], heads inside each (:172)
+        qkv = linear(y, self.qkv.weight, self.qkv.bias, once=once)            # columns [q | k | v], heads inside each (:172)
         if seg is None:
             seg = ops.Segments.dense(B, N, y.device)
         a = ops.mha_self(qkv, H, C // H, seg, self.scale)
-        return linear(a, self.proj.weight, self.proj.bias)
+        return linear(a, self.proj.weight, self.proj.bias, once=once)
 
     def forward(self, x):
         B, N, C = x.shape
@@ -96,15 +96,15 @@ class Block(nn.Module):          # multimae_utils.py:217-232
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
 
-    def forward_rows(self, x, delta, B, N, seg=None):
+    def forward_rows(self, x, delta, B, N, seg=None, once=False):
         """Residual stream x (B*N, C) fp32 plus a pending delta (compute dtype or None).  Returns (x, delta)."""
         T = compute_dtype(self.attn.qkv.weight)
         (x,), y = ops.parts_add_ln([x], delta, [0 if delta is not None else -1], self.norm1.weight, self.norm1.bias,
                                    eps1=self.norm1.eps, out_dtype=T)
-        a = self.attn.forward_rows(y, B, N, seg)
+        a = self.attn.forward_rows(y, B, N, seg, once)
         (x,), y = ops.parts_add_ln([x], a, [0], self.norm2.weight, self.norm2.bias, eps1=self.norm2.eps, out_dtype=T)
-        h = linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias)
-        f = linear(ops.gelu(h), self.mlp.fc2.weight, self.mlp.fc2.bias)
+        h = linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, once=once)
+        f = linear(ops.gelu(h), self.mlp.fc2.weight, self.mlp.fc2.bias, once=once)
         return x, f
 
     def forward(self, x):

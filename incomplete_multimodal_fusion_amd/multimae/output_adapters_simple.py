@@ -63,19 +63,20 @@ class SpatialOutputAdapter(nn.Module):
     def no_weight_decay(self):
         return {'pos_emb', 'task_embeddings'}
 
-    def forward_tokens(self, enc_rows: torch.Tensor, B: int, P: int, seg=None) -> torch.Tensor:
-        """enc_rows (B*P, D_enc) in the compute dtype -> out_proj tokens (B*P, C*P_H*P_W) in (c ph pw) order."""
+    def forward_tokens(self, enc_rows: torch.Tensor, B: int, P: int, seg=None, once: bool = False) -> torch.Tensor:
+        """enc_rows (B*P, D_enc) in the compute dtype -> out_proj tokens (B*P, C*P_H*P_W) in (c ph pw) order.
+        once: this adapter runs exactly once in the current optimizer step (see ops.linear)."""
         assert self.dim_tokens_enc is not None, 'Need to call init(dim_tokens_enc) function first'
-        ctx = linear(enc_rows, self.proj_context.weight, self.proj_context.bias)
+        ctx = linear(enc_rows, self.proj_context.weight, self.proj_context.bias, once=once)
         x = ctx.float()
         if self.task_embeddings is not None and self.task in self.task_embeddings:
             x = x + self.task_embeddings[self.task].reshape(1, -1)
         delta = None
         if isinstance(self.decoder_transformer, nn.Sequential):
             for blk in self.decoder_transformer:
-                x, delta = blk.forward_rows(x, delta, B, P, seg)
+                x, delta = blk.forward_rows(x, delta, B, P, seg, once)
         y = x if delta is None else x + delta.float()
-        return linear(wcast(y, enc_rows.dtype), self.out_proj.weight, self.out_proj.bias)
+        return linear(wcast(y, enc_rows.dtype), self.out_proj.weight, self.out_proj.bias, once=once)
 
     def forward(self, encoder_tokens: torch.Tensor, input_info: Dict, ids_keep: torch.Tensor = None,
                 ids_restore: torch.Tensor = None):

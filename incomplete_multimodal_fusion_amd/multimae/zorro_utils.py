@@ -43,10 +43,10 @@ def wcast(w: torch.Tensor, dtype) -> torch.Tensor:
     return w if w.dtype == dtype else w.to(dtype)
 
 
-def linear(x, weight, bias=None, side_wgrad=False):
+def linear(x, weight, bias=None, side_wgrad=False, once=False):
     """Dense projection: library GEMMs (hipBLASLt/rocBLAS through torch) for y and dx, split-K batched GEMM with an fp32
     sum for the weight gradient (ops._Linear).  `weight` may be a list of master weights to be row-concatenated."""
-    return ops.linear(x, weight, bias, side_wgrad)
+    return ops.linear(x, weight, bias, side_wgrad, once)
 
 
 def segments_from_mask(mask: torch.Tensor, B: int):

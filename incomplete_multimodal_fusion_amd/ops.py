@@ -123,13 +123,23 @@ class _Linear(torch.autograd.Function):
     compute dtype here); the weight gradient comes back in fp32 straight from a split-K batched GEMM."""
 
     @staticmethod
-    def forward(ctx, x, bias, side, *ws):
+    def forward(ctx, x, bias, flags, *ws):
+        side, once = flags
+        from .engine import grad_view_of, shadow_of
         T = x.dtype
-        w = ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
-        w = w if w.dtype == T else w.to(T)
+        w = shadow_of(ws, T)                      # bf16 shadow kept fresh by the fused optimizer: no cast kernel
+        if w is None:
+            w = ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+            w = w if w.dtype == T else w.to(T)
+        b = None
+        if bias is not None:
+            b = bias._mmae_shadow if (T == torch.bfloat16 and hasattr(bias, "_mmae_shadow")) else \
+                (bias if bias.dtype == T else bias.to(T))
         with torch.autocast("cuda", enabled=False):
-            y = torch.nn.functional.linear(x, w, None if bias is None else (bias if bias.dtype == T else bias.to(T)))
+            y = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
+        # in-place flat gradient only for weights used ONCE per step: a second use would overwrite the first gradient
+        ctx.gview = grad_view_of(ws) if (once and all(wi.dtype == torch.float32 for wi in ws)) else None
         ctx.meta = ([wi.shape[0] for wi in ws], [wi.dtype for wi in ws], bias is not None and bias.dtype, side)
         return y
 
@@ -160,11 +170,14 @@ class _Linear(torch.autograd.Function):
                     ss.wait_stream(main)
                     g2.record_stream(ss); x2.record_stream(ss)
                 with torch.cuda.stream(ss) if use_side else _NullCtx():
+                    gview = ctx.gview               # flat fp32 gradient buffer of the optimizer engine (or None)
                     if S > 1:
-                        gw = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in)) \
-                            .sum(0, dtype=torch.float32)
+                        part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
+                        gw = torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else \
+                            part.sum(0, dtype=torch.float32)
                     else:
-                        gw = torch.mm(g2.t(), x2).float()
+                        gw = torch.mm(g2.t(), x2)
+                        gw = gview.copy_(gw) if gview is not None else gw.float()
                     off = 0
                     for i, n in enumerate(sizes):
                         if ctx.needs_input_grad[3 + i]:
@@ -188,12 +201,14 @@ class _NullCtx:
         return False
 
 
-def linear(x, weight, bias=None, side_wgrad=False):
+def linear(x, weight, bias=None, side_wgrad=False, once=False):
     """weight: one (N, K) master weight or a list of them (row-concatenated, e.g. [to_q.weight, to_kv.weight]).
-    side_wgrad: the weights are used exactly once per step, so their gradient GEMM may run on the side stream; the
-    caller must join_wgrad_stream() before the gradients are read (PretrainStep / GradAllReducer do)."""
+    once: these weights are used exactly once per optimizer step -- their fp32 gradient may then be written straight
+    into the optimizer engine's flat buffer (engine.FlatAdamW) instead of a fresh tensor that autograd accumulates.
+    side_wgrad (needs once): the gradient GEMM may run on the side stream; the caller must join_wgrad_stream() before
+    the gradients are read (PretrainStep / GradAllReducer do)."""
     ws = weight if isinstance(weight, (list, tuple)) else (weight,)
-    return _Linear.apply(x, bias, bool(side_wgrad), *ws)
+    return _Linear.apply(x, bias, (bool(side_wgrad) and bool(once), bool(once)), *ws)
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -91,7 +91,7 @@ class PretrainStep:
             out = self.model(x, task_masks=task_masks, num_encoded_tokens=self.N, alphas=self.alphas,
                              sample_tasks_uniformly=self.uniform)
             task_losses, loss_contra, loss = step_losses(out, tasks_dict, out[1], self.patch, self.loss_fns)
-        self.opt.zero_grad(set_to_none=True)
+        self.opt.zero_grad(set_to_none=True)               # (FlatAdamW: also clears the flat gradient buffer)
         if self.reducer is not None:
             self.reducer.prepare()
         loss.backward()
