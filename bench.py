@@ -81,6 +81,21 @@ def cpu_baseline(args):
                       (args.model, args.input_size, args.input_size, B, N, len(times), t)}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the roofline kernel from the committed PMC summary of THIS command (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/r01_pmc_hbm.json) -- the counters
+    cannot be collected from inside the process.  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        for name, v in ks.items():
+            if kernel_substr in name:
+                return round(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,9 +200,12 @@ def main():
                                       3 * (args.input_size // 16) ** 2),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
-            "roofline": {"kernel": "mha_fwd_kernel<bf16,64>" if not args.fp32 else "mha_fwd_kernel<f32,64>",
+            "roofline": {"kernel": "mha_bf16_fwd_kernel<64, 4>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                         "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
+                         "traffic": pmc_traffic("mha_bf16_fwd_kernel<64") if (not args.fp32 and args.batch == 256) else None,
+                         "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
+                         "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 512 * 2,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
