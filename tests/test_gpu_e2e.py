@@ -76,12 +76,13 @@ def test_e2e_golden(g_e2e, case, mode):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_e2e_vs_oracle_multitile(mode):
-    """256x256 tiles (P=256, N=384, S=640: several 64-row attention tiles, uneven modality split), D=128, 2 heads of
-    64, depth 2, decoder 64/1/2; the oracle runs the same weights on CPU in fp32."""
+@pytest.mark.parametrize("mode,width", [("fp32", 128), ("bf16", 128), ("bf16", 1024)])
+def test_e2e_vs_oracle_multitile(mode, width):
+    """256x256 tiles (P=256, N=384, S=640: several 64-row attention tiles, uneven modality split), 2 heads of 64,
+    depth 2, decoder 64/1/2; the oracle runs the same weights on CPU in fp32.  width 1024 = ViT-Large token width:
+    4-chunk LayerNorm path and the odd GEGLU width ffi = int(1024*8/3) = 2730."""
     torch.manual_seed(11)
-    cfg = dict(dim_tokens=128, depth=2, dim_head=64, heads=2, image_size=256, patch_size=16, decoder_dim=64,
+    cfg = dict(dim_tokens=width, depth=2, dim_head=64, heads=2, image_size=256, patch_size=16, decoder_dim=64,
                decoder_depth=1, decoder_heads=2)
     channels = (("s1", 1), ("s2", 3), ("dem", 1))
     model = build_model(cfg, channels)
