@@ -285,8 +285,8 @@ class MultiMAE(nn.Module):
             dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
             (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
                                               fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
-            kv = linear(z, fus.attn.to_kv.weight, side_wgrad=sw, once=True)                                           # K/V of every slot source
-            q = linear(z[BN:BN + BP], fus.attn.to_q.weight, side_wgrad=sw, once=True)                                 # fusion slot queries only
+            # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
+            kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
             a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
             o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
             (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)

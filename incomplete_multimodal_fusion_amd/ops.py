@@ -157,8 +157,6 @@ class _Linear(torch.autograd.Function):
             gx = torch.nn.functional.linear(g2, w.t().contiguous()).reshape(x.shape) if ctx.needs_input_grad[0] else None
             gws = [None] * len(sizes)
             if any(ctx.needs_input_grad[3:]):
-                rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
-                S = _split_k(rows, n_out, n_in)
                 # The weight gradient is off the critical path (nothing in this backward pass reads it) and MFMA-bound,
                 # while the kernels that follow on the main stream (GEGLU / LayerNorm / attention backward) are
                 # HBM-bound: issue it on a side stream so the two classes overlap.  Only for weights used once per step
@@ -170,14 +168,7 @@ class _Linear(torch.autograd.Function):
                     ss.wait_stream(main)
                     g2.record_stream(ss); x2.record_stream(ss)
                 with torch.cuda.stream(ss) if use_side else _NullCtx():
-                    gview = ctx.gview               # flat fp32 gradient buffer of the optimizer engine (or None)
-                    if S > 1:
-                        part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
-                        gw = torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else \
-                            part.sum(0, dtype=torch.float32)
-                    else:
-                        gw = torch.mm(g2.t(), x2)
-                        gw = gview.copy_(gw) if gview is not None else gw.float()
+                    gw = _wgrad(g2, x2, ctx.gview)   # ctx.gview: flat fp32 gradient buffer of the optimizer engine (or None)
                     off = 0
                     for i, n in enumerate(sizes):
                         if ctx.needs_input_grad[3 + i]:
@@ -199,6 +190,58 @@ class _NullCtx:
 
     def __exit__(self, *a):
         return False
+
+
+def _wgrad(g2, x2, gview):
+    """dW = g2^T x2 in fp32 (split-K batched GEMM + sum), written into `gview` when given."""
+    rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
+    S = _split_k(rows, n_out, n_in)
+    if S > 1:
+        part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
+        return torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else part.sum(0, dtype=torch.float32)
+    gw = torch.mm(g2.t(), x2)
+    return gview.copy_(gw) if gview is not None else gw.float()
+
+
+class _KvQ(torch.autograd.Function):
+    """Block_Fusion projections in one node: kv = z @ Wkv^T over ALL rows, q = z[r0:r0+n] @ Wq^T over the fusion rows.
+    One node instead of two Linear nodes on z and a slice of z: the backward adds the query path into the slice of dz in
+    place (addmm) instead of autograd zero-filling a full-size gradient for the slice and summing two (rows, D) tensors."""
+
+    @staticmethod
+    def forward(ctx, z, r0, n, wq, wkv):
+        from .engine import grad_view_of, shadow_of
+        T = z.dtype
+        wq_c = shadow_of((wq,), T)
+        wq_c = wq_c if wq_c is not None else (wq if wq.dtype == T else wq.to(T))
+        wkv_c = shadow_of((wkv,), T)
+        wkv_c = wkv_c if wkv_c is not None else (wkv if wkv.dtype == T else wkv.to(T))
+        with torch.autocast("cuda", enabled=False):
+            kv = torch.nn.functional.linear(z, wkv_c)
+            q = torch.nn.functional.linear(z[r0:r0 + n], wq_c)
+        ctx.save_for_backward(z, wq_c, wkv_c)
+        ctx.cfg = (r0, n, grad_view_of((wq,)) if wq.dtype == torch.float32 else None,
+                   grad_view_of((wkv,)) if wkv.dtype == torch.float32 else None, wq.dtype, wkv.dtype)
+        return kv, q
+
+    @staticmethod
+    def backward(ctx, gkv, gq):
+        z, wq_c, wkv_c = ctx.saved_tensors
+        r0, n, gvq, gvkv, dq_, dkv_ = ctx.cfg
+        gkv = gkv if gkv.is_contiguous() else gkv.contiguous()
+        gq = gq if gq.is_contiguous() else gq.contiguous()
+        with torch.autocast("cuda", enabled=False):
+            gz = torch.nn.functional.linear(gkv, wkv_c.t().contiguous())
+            zs = gz[r0:r0 + n]
+            torch.addmm(zs, gq, wq_c, out=zs)
+            gwkv = _wgrad(gkv, z, gvkv)
+            gwq = _wgrad(gq, z[r0:r0 + n], gvq)
+        return gz, None, None, gwq if gwq.dtype == dq_ else gwq.to(dq_), gwkv if gwkv.dtype == dkv_ else gwkv.to(dkv_)
+
+
+def kv_q_projections(z, r0, n, wq, wkv):
+    """-> (kv over all rows of z, q over rows [r0, r0+n)).  Both weights must be used once per step (see linear())."""
+    return _KvQ.apply(z, r0, n, wq, wkv)
 
 
 def linear(x, weight, bias=None, side_wgrad=False, once=False):
