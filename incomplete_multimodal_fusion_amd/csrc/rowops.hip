@@ -105,23 +105,30 @@ struct AddLnBwd {
     long rows; int D;
 };
 
-template <typename TD, typename TY, int NC, bool DOUBLE>
+// HASB: some beta exists (decoder nn.LayerNorm) -> keep the dbeta accumulators; the encoder's bias-less LayerNorms
+// instantiate HASB = false and save 36 VGPRs.  gamma/beta vectors live in LDS (staged once per block) instead of
+// registers: 170 -> ~100 VGPRs, i.e. 4 resident waves per SIMD instead of 2 for this persistent grid-stride kernel.
+template <typename TD, typename TY, int NC, bool DOUBLE, bool HASB>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][D]
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][D] reduction scratch, then g1, g2, b1 [D] each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = p.D;
     const float invD = 1.f / (float)D;
-    f32x4 dg1[NC], db1[NC], dg2[NC], db2[NC], G1[NC], G2[NC], B1[NC];
+    float* sg1 = red + 4 * D; float* sg2 = sg1 + D; float* sb1 = sg2 + D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        sg1[c] = p.g1[c];
+        sg2[c] = DOUBLE ? p.g2[c] : 0.f;
+        sb1[c] = (HASB && p.b1) ? p.b1[c] : 0.f;
+    }
+    __syncthreads();
+    f32x4 dg1[NC], dg2[DOUBLE ? NC : 1], db1[HASB ? NC : 1], db2[(HASB && DOUBLE) ? NC : 1];
+    const f32x4 z4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int col = 4 * (lane + 64 * c);
-        const f32x4 z{0.f, 0.f, 0.f, 0.f};
-        dg1[c] = z; db1[c] = z; dg2[c] = z; db2[c] = z; G1[c] = z; G2[c] = z; B1[c] = z;
-        if (col < D) {
-            G1[c] = ld4f<float>(p.g1 + col);
-            if (p.b1) B1[c] = ld4f<float>(p.b1 + col);
-            if (DOUBLE) G2[c] = ld4f<float>(p.g2 + col);
-        }
+        dg1[c] = z4;
+        if (DOUBLE) dg2[c] = z4;
+        if (HASB) db1[c] = z4;
+        if (HASB && DOUBLE) db2[c] = z4;
     }
     for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
         const f32x4 st = *reinterpret_cast<const f32x4*>(p.stats + row * 4);
@@ -131,14 +138,18 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int col = 4 * (lane + 64 * c);
-            xh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[c] = xh[c];
+            xh[c] = z4; gv[c] = z4;
             if (col < D) {
                 xh[c] = (ld4f<float>(p.x_new + row * D + col) - m1) * r1;
                 const f32x4 gy = ld4f<TY>(reinterpret_cast<const TY*>(p.gy) + row * D + col);
                 if (DOUBLE) {
-                    const f32x4 uh = (xh[c] * G1[c] + B1[c] - m2) * r2;
-                    dg2[c] += gy * uh; db2[c] += gy;
-                    const f32x4 guh = gy * G2[c];
+                    const f32x4 G1 = *reinterpret_cast<const f32x4*>(sg1 + col);
+                    f32x4 u = xh[c] * G1;
+                    if (HASB) u += *reinterpret_cast<const f32x4*>(sb1 + col);
+                    const f32x4 uh = (u - m2) * r2;
+                    dg2[c] += gy * uh;
+                    if (HASB) db2[c] += gy;
+                    const f32x4 guh = gy * *reinterpret_cast<const f32x4*>(sg2 + col);
                     gv[c] = guh;
                     a += sum4(guh); bsum += sum4(guh * uh);
                 } else {
@@ -152,7 +163,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
             for (int c = 0; c < NC; ++c) {
                 const int col = 4 * (lane + 64 * c);
                 if (col < D) {
-                    const f32x4 uh = (xh[c] * G1[c] + B1[c] - m2) * r2;
+                    f32x4 u = xh[c] * *reinterpret_cast<const f32x4*>(sg1 + col);
+                    if (HASB) u += *reinterpret_cast<const f32x4*>(sb1 + col);
+                    const f32x4 uh = (u - m2) * r2;
                     gv[c] = (gv[c] - c1 - uh * c2) * r2;      // grad wrt u
                 }
             }
@@ -162,8 +175,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
         for (int c = 0; c < NC; ++c) {
             const int col = 4 * (lane + 64 * c);
             if (col < D) {
-                dg1[c] += gv[c] * xh[c]; db1[c] += gv[c];
-                gv[c] = gv[c] * G1[c];                        // grad wrt xhat
+                dg1[c] += gv[c] * xh[c];
+                if (HASB) db1[c] += gv[c];
+                gv[c] = gv[c] * *reinterpret_cast<const f32x4*>(sg1 + col);   // grad wrt xhat
                 a3 += sum4(gv[c]); a4 += sum4(gv[c] * xh[c]);
             }
         }
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
             }
         }
     }
-    // block reduction of the four column-sum vectors, one after the other
+    // block reduction of the column-sum vectors, one after the other: [dg1, db1, dg2, db2]
 #pragma unroll
     for (int qn = 0; qn < 4; ++qn) {
         if (!DOUBLE && qn >= 2) break;
@@ -188,7 +202,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
         for (int c = 0; c < NC; ++c) {
             const int col = 4 * (lane + 64 * c);
             if (col < D) {
-                const f32x4 val = qn == 0 ? dg1[c] : qn == 1 ? db1[c] : qn == 2 ? dg2[c] : db2[c];
+                f32x4 val = z4;
+                if (qn == 0) val = dg1[c];
+                else if (qn == 1) { if (HASB) val = db1[c]; }
+                else if (qn == 2) { if (DOUBLE) val = dg2[c]; }
+                else { if (HASB && DOUBLE) val = db2[c]; }
                 *reinterpret_cast<f32x4*>(red + wave * D + col) = val;
             }
         }
@@ -243,17 +261,21 @@ static int add_ln_fwd_nc(const AddLnFwd& p, hipStream_t st) {
     return MMAE_OK;
 }
 template <typename TD, typename TY, bool DOUBLE>
-static int add_ln_bwd_nc(const AddLnBwd& p, int nblk, hipStream_t st) {
+static int add_ln_bwd_nc(const AddLnBwd& p, int nblk, bool hasb, hipStream_t st) {
     const int nc = cdiv(p.D, 256);
     dim3 grid(nblk), blk(256);
-    const size_t lds = (size_t)4 * p.D * sizeof(float);
+    const size_t lds = (size_t)7 * p.D * sizeof(float);
+#define GO(NCV)                                                                                           \
+    if (hasb) hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, true>), grid, blk, lds, st, p);  \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, false>), grid, blk, lds, st, p);
     switch (nc) {
-        case 1: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 1, DOUBLE>), grid, blk, lds, st, p); break;
-        case 2: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 2, DOUBLE>), grid, blk, lds, st, p); break;
-        case 3: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 3, DOUBLE>), grid, blk, lds, st, p); break;
-        case 4: hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, 4, DOUBLE>), grid, blk, lds, st, p); break;
+        case 1: GO(1) break;
+        case 2: GO(2) break;
+        case 3: GO(3) break;
+        case 4: GO(4) break;
         default: return MMAE_ERR_ARG;
     }
+#undef GO
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -294,7 +316,9 @@ extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, c
     long nblk = (rows + 3) / 4; if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
     AddLnBwd p{x_new, gy, gx_up, gamma1, beta1, gamma2, stats, gx, gdelta, ws, rows, D};
     const bool dbl = gamma2 != nullptr;
-    int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, st);
+    // dbeta outputs are only produced (non-zero) when the kernel keeps beta accumulators
+    const bool hasb = beta1 != nullptr || dbeta1 != nullptr || dbeta2 != nullptr;
+    int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, hasb, st);
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
                        dgamma1, dbeta1, dgamma2, dbeta2, accumulate);
