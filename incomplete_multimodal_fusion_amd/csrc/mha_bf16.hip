@@ -9,6 +9,8 @@
 //     columns 4p..4p+3, and lane i receives column i of the 4 rows.
 //   * the next tile is prefetched into registers while the current one is computed (one LDS buffer, two barriers per tile);
 //   * softmax in the exp2 domain with one fma per score, and the key-bound mask only on a segment's ragged last tile.
+// Tried and rejected (tools/bench_attn.py, one process): prefetch distance 2 (-4 %), 128-row query tiles / 8 waves (+-0),
+// one persistent block per (sample, head) pair (-17 %: many short blocks overlap better than few long ones).
 #include "mha_common.hpp"
 #include "mmae_hip.h"
 
@@ -300,6 +302,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
     }
 }
 
+// __launch_bounds__(.., 2): at most 256 registers per lane, so the compiler selects the VGPR form of the MFMAs -- with the
+// default budget it parks accumulators in AGPRs and pays ~80 v_accvgpr_read/write per tile around the softmax.
 // ------------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 // No per-element masks: rows of a ragged tile beyond its length are ZERO in the LDS images, so a padded key has K = V = 0
 // and contributes K^T dS = 0 to dQ whatever its (finite) dS is.

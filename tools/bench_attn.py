@@ -55,6 +55,11 @@ def run(variant):
     return e[0].elapsed_time(e[1]) / a.iters * 1e3, e[1].elapsed_time(e[2]) / a.iters * 1e3
 
 variants = [int(v) for v in a.variants.split(",")]
+if has_var and len(variants) > 1:       # agreement of every variant's forward output with the first one
+    lib.mmae_mha_set_variant(variants[0]); ref = ops.mha_self(qkv, H, dh, seg, dh ** -0.5).float()
+    for v in variants[1:]:
+        lib.mmae_mha_set_variant(v); o = ops.mha_self(qkv, H, dh, seg, dh ** -0.5).float()
+        print("variant %d vs %d: max |diff| %.3e" % (v, variants[0], float((o - ref).abs().max())), flush=True)
 res = {v: [] for v in variants}
 for r in range(a.rounds):
     for v in variants:
