@@ -160,13 +160,14 @@ def main():
     torch.manual_seed(4321 + rank)
 
     prof = ops.KernelTimer("mmae_mha_fwd")
+    prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
     for _ in range(args.warmup):
         losses = step(x)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.set_kernel_timer(prof)
+    ops.set_kernel_timer([prof, prof_ln])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step(x)
@@ -190,6 +191,8 @@ def main():
         # roofline of the fused attention kernel: mask-aware algorithmic FLOPs per launch
         # 4 * dh * h * sum_b (sum_m N_m^2 + P * S)   (SURVEY.md 8d), accumulated on the device per launch
         ach = flops / n_launch / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+        ln_ms, ln_n, ln_bytes = prof_ln.summary()
+        ln_gbs = ln_bytes / ln_n / (ln_ms * 1e-3) / 1e9 if ln_n else 0.0
         out = {
             "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -200,7 +203,16 @@ def main():
                                       3 * (args.input_size // 16) ** 2),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
-            "roofline": {"kernel": "mha_bf16_fwd_kernel<64, 4>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
+            # dominant hand-written kernel by total time (profiles/r01_kernel_stats.md): the fused residual-add +
+            # double-LayerNorm backward, HBM-bound.  achieved = algorithmic bytes of the launch / its HIP-event time.
+            "roofline": {"kernel": "add_ln_bwd_kernel<bf16,bf16,3,double,nobeta>" if not args.fp32 else "add_ln_bwd_kernel<f32,...>",
+                         "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("add_ln_bwd_kernel") if (not args.fp32 and args.batch == 256) else None,
+                         "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
+                         "avg_launch_ms": round(ln_ms, 4), "launches": ln_n},
+            # the flagship MFMA kernel of the path (north_star: fusion-attention block), mask-aware algorithmic FLOPs
+            "roofline_attention": {"kernel": "mha_bf16_fwd_kernel<64, 4>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
                          "traffic": pmc_traffic("mha_bf16_fwd_kernel<64") if (not args.fp32 and args.batch == 256) else None,

@@ -24,7 +24,8 @@ def _rowmat(t, cols_needed):
 
 # ------------------------------------------------------------------------------------------------ kernel timing hook
 class KernelTimer:
-    """HIP-event timing of one C-ABI entry point on the stream it is launched on (bench.py's roofline leg)."""
+    """HIP-event timing of one C-ABI entry point on the stream it is launched on (bench.py's roofline leg).
+    `flops` accumulates the algorithmic work of the timed launches (FLOPs or bytes, a device scalar or a python number)."""
 
     def __init__(self, name: str):
         self.name, self.pairs, self.flops = name, [], None
@@ -42,15 +43,20 @@ class KernelTimer:
         if not self.pairs:
             return 0.0, 0, 0.0
         ms = [a.elapsed_time(b) for a, b in self.pairs]
-        return sum(ms) / len(ms), len(ms), float(self.flops.item()) if self.flops is not None else 0.0
+        work = 0.0 if self.flops is None else float(self.flops.item() if torch.is_tensor(self.flops) else self.flops)
+        return sum(ms) / len(ms), len(ms), work
 
 
-_TIMER = None
+_TIMER = None          # attention forward
+_TIMERS = {}           # other entry points by name
 
 
 def set_kernel_timer(t):
-    global _TIMER
-    _TIMER = t
+    """t: one KernelTimer, a list of them, or None."""
+    global _TIMER, _TIMERS
+    ts = [] if t is None else (list(t) if isinstance(t, (list, tuple)) else [t])
+    _TIMER = next((x for x in ts if x.name == "mmae_mha_fwd"), None)
+    _TIMERS = {x.name: x for x in ts if x.name != "mmae_mha_fwd"}
 
 
 # ------------------------------------------------------------------------------------------------ segments
@@ -426,10 +432,20 @@ class _PartsAddLN(torch.autograd.Function):
                 continue
             gx = torch.empty_like(xn) if need_gx else None
             gd = ctypes.c_void_p(gdelta.data_ptr() + off * D * gdelta.element_size()) if off >= 0 else None
+            tm = _TIMERS.get("mmae_add_ln_bwd")
+            if tm is not None:
+                # algorithmic bytes: x_new (4) + gy + [gx_up (4)] read, [gx (4)] + [gdelta] written, per element
+                per = 4 + gy.element_size() + (4 if up is not None else 0) + (4 if gx is not None else 0) + \
+                    (gdelta.element_size() if off >= 0 else 0)
+                tm.add_flops(float(n) * D * per)
+                ev0, ev1 = tm.bracket()
+                ev0.record()
             call("mmae_add_ln_bwd", ddt, dt(out_dtype), n, D, ptr(xn),
                  ctypes.c_void_p(gy.data_ptr() + r0 * D * gy.element_size()), ptr(_c(up)) if up is not None else None,
                  ptr(g1), ptr(b1), ptr(g2), ctypes.c_void_p(stats.data_ptr() + r0 * 16), ptr(gx), gd, ptr(acc[0]),
                  ptr(acc[1]), ptr(acc[2]), ptr(acc[3]), ptr(ws), 0 if first else 1, stream())
+            if tm is not None:
+                ev1.record()
             first = False
             gxs.append(gx)
             r0 += n
