@@ -1,0 +1,105 @@
+"""Checkpoint format compatible with the reference trainer.
+
+Reference: pretraining/utils/checkpoint.py -- save_model (:75-100) writes
+`output_dir/checkpoint-{epoch}.pth` = {'model', 'optimizer', 'epoch', 'scaler', 'args'[, 'loss_balancer']} from rank 0
+only; auto_load_model (:103-152) resumes from the highest-numbered file, restores model / optimizer / scaler and sets
+args.start_epoch = epoch + 1.  Consumers of the 'model' entry: pretraining/infer_mmae.py:146-147 (strict load) and the
+downstream backbone (downstream/.../multimae_big_imcomplete.py:456-460).
+
+The 'model' entry is the module's own state_dict (reference key names / shapes, tested by
+tests/test_cabi_symbols.py).  The 'optimizer' entry is written in torch.optim.AdamW's state_dict layout even when the
+fused flat engine (engine.FlatAdamW) produced it, so either optimizer can resume from either file.
+"""
+import glob
+import os
+import re
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _is_main() -> bool:
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def optimizer_state_dict(optimizer, model) -> dict:
+    """torch.optim.AdamW-layout state for a torch optimizer or an engine.FlatAdamW over model.parameters()."""
+    if isinstance(optimizer, torch.optim.Optimizer):
+        return optimizer.state_dict()
+    params = list(model.parameters())
+    idx = {id(p): i for i, p in enumerate(params)}
+    state = {}
+    for p in optimizer.params:
+        o = optimizer.offsets[id(p)]
+        sl = slice(o, o + p.numel())
+        state[idx[id(p)]] = {"step": torch.tensor(float(optimizer.steps)),
+                             "exp_avg": optimizer.exp_avg[sl].view_as(p).detach().clone(),
+                             "exp_avg_sq": optimizer.exp_avg_sq[sl].view_as(p).detach().clone()}
+    g = optimizer.param_groups[0]
+    group = {"lr": g["lr"], "betas": tuple(optimizer.betas), "eps": optimizer.eps, "weight_decay": g["weight_decay"],
+             "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+             "fused": None, "lr_scale": g.get("lr_scale", 1.0), "params": list(range(len(params)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_optimizer_state_dict(optimizer, model, sd: dict):
+    if isinstance(optimizer, torch.optim.Optimizer):
+        optimizer.load_state_dict(sd)
+        return
+    params = list(model.parameters())
+    steps = 0
+    for i, st in sd["state"].items():
+        p = params[int(i)]
+        if id(p) not in optimizer.offsets:
+            continue
+        o = optimizer.offsets[id(p)]
+        optimizer.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+        optimizer.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+        steps = max(steps, int(float(st["step"])))
+    optimizer.steps = steps
+    g = sd["param_groups"][0]
+    optimizer.param_groups[0]["lr"] = g["lr"]
+    optimizer.param_groups[0]["weight_decay"] = g["weight_decay"]
+    optimizer.refresh_shadow()
+
+
+def save_model(output_dir: str, epoch: int, model, optimizer, args=None, loss_scaler=None, loss_balancer=None) -> Optional[str]:
+    """checkpoint.py:75-93 -- rank 0 only."""
+    if not _is_main():
+        return None
+    os.makedirs(output_dir, exist_ok=True)
+    to_save = {"model": model.state_dict(), "optimizer": optimizer_state_dict(optimizer, model), "epoch": epoch,
+               "scaler": loss_scaler.state_dict() if loss_scaler is not None else {}, "args": args}
+    if loss_balancer is not None:
+        to_save["loss_balancer"] = loss_balancer.state_dict()
+    path = os.path.join(output_dir, "checkpoint-%s.pth" % str(epoch))
+    torch.save(to_save, path)
+    return path
+
+
+def latest_checkpoint(output_dir: str) -> Optional[str]:
+    """Highest-numbered checkpoint-*.pth (checkpoint.py:107-117)."""
+    best, best_path = -1, None
+    for f in glob.glob(os.path.join(output_dir, "checkpoint-*.pth")):
+        m = re.search(r"checkpoint-(\d+)\.pth$", f)
+        if m and int(m.group(1)) > best:
+            best, best_path = int(m.group(1)), f
+    return best_path
+
+
+def auto_load_model(output_dir: str, model, optimizer=None, loss_scaler=None, resume: str = "", map_location="cpu") -> int:
+    """Returns the epoch to start from (0 when nothing was found).  checkpoint.py:103-132."""
+    path = resume or (latest_checkpoint(output_dir) if output_dir else None)
+    if not path:
+        return 0
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ckpt["model"], strict=True)
+    if optimizer is not None and "optimizer" in ckpt and "epoch" in ckpt:
+        load_optimizer_state_dict(optimizer, model, ckpt["optimizer"])
+        if loss_scaler is not None and ckpt.get("scaler"):
+            loss_scaler.load_state_dict(ckpt["scaler"])
+        return int(ckpt["epoch"]) + 1
+    if hasattr(optimizer, "refresh_shadow"):
+        optimizer.refresh_shadow()
+    return 0
