@@ -328,6 +328,74 @@ def gen_masks(ref):
     print("masks.npz:", len(bag), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+DS_CFG = dict(dim_tokens=32, depth=4, dim_head=32, heads=2, image_size=64, patch_size=16)
+
+
+def gen_downstream():
+    """ViTBaseline.forward_features / forward (multimae_big_imcomplete.py:534-680): per-forward modality
+    subset (absent modalities get NO slot in the modality attention), feature taps after layers `flags`, norm + necks."""
+    ds = ref_loader.load_downstream()
+    torch.manual_seed(17)
+    model = ref_loader.build_downstream_backbone(ds, channels=CHANNELS, **DS_CFG)
+    gen = torch.Generator().manual_seed(5)
+    rand_init_(model, gen, scale=0.3)
+    with torch.no_grad():
+        model.mask_embedding.add_(0.05 * torch.randn(model.mask_embedding.shape, generator=gen))
+    B, P = 2, 16
+    x = {d: torch.randn(B, c, 64, 64, generator=gen) for d, c in CHANNELS}
+    bag = Bag()
+    bag["config"] = np.array(json.dumps(dict(DS_CFG, channels=CHANNELS, B=B, flags=list(model.flags))))
+    for k, v in model.state_dict().items():
+        bag["state/" + k] = npy(v)
+    for d in x:
+        bag["x/" + d] = npy(x[d])
+    # eval: all modalities, every token kept (mask_inputs False)
+    model.eval()
+    with torch.no_grad():
+        outs, nh, nw = model.forward_features(x)
+        feats = model(x)
+    for i, o in enumerate(outs):
+        bag["eval_all/tap%d" % i] = npy(o)
+    for i, f in enumerate(feats):
+        bag["eval_all/feat%d" % i] = npy(f)
+    # training-style subsets with explicit 90 % masks (int(M'*P*0.9) kept, :579); the subset itself is what the
+    # reference draws with random.sample (:542-544) -- pinned here by seeding `random`
+    import random
+    model.train()
+    for seed in (1, 2, 5):
+        random.seed(seed)
+        n = random.randint(1, 3); subset = random.sample(model.in_domains, n)
+        present = [d for d in model.in_domains if d in subset]           # OrderedDict order of x (:560-564)
+        N = int(len(present) * P * 0.9)
+        masks, left = {}, N
+        for j, d in enumerate(present):
+            k = left if j == len(present) - 1 else min(P, max(0, N // len(present) + (j % 2) * 2 - 1))
+            k = min(k, P); left -= k
+            row = torch.ones(P, dtype=torch.long); row[torch.randperm(P, generator=gen)[:k]] = 0
+            masks[d] = row[None].repeat(B, 1)
+        assert left == 0
+        random.seed(seed)
+        model.zero_grad()
+        outs, nh, nw = model.forward_features(x, task_masks=masks)
+        assert list(model.incomplete_domains) == subset
+        loss = sum((o * o).mean() for o in outs)
+        loss.backward()
+        pre = "train_seed%d/" % seed
+        bag[pre + "present"] = np.array(json.dumps(present))
+        bag[pre + "N"] = np.array(N)
+        for d in present:
+            bag[pre + "mask/" + d] = npy(masks[d])
+        for i, o in enumerate(outs):
+            bag[pre + "tap%d" % i] = npy(o)
+        bag[pre + "loss"] = npy(loss)
+        for n_, p_ in model.named_parameters():
+            if p_.grad is not None and ("blocks.0." in n_ or "fus_blocks.3." in n_ or n_ in ("mask_embedding", "fusion_tokens")):
+                bag[pre + "grad/" + n_] = npy(p_.grad)
+    np.savez_compressed(os.path.join(OUT, "downstream.npz"), **bag)
+    print("downstream.npz:", len(bag), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -335,5 +403,6 @@ if __name__ == "__main__":
     gen_ops(ref)
     gen_e2e(ref)
     gen_masks(ref)
+    gen_downstream()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

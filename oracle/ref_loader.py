@@ -99,3 +99,46 @@ def build_reference_model(ref, *, dim_tokens, depth, dim_head, heads, image_size
                             return_token_types=(T.S1, T.S2, T.DEM, T.FUSION),
                             drop_path_rate=0.0, norm_layer=ref.zu.LayerNorm)
     return model
+
+
+_ds_cache = None
+
+
+def load_downstream():
+    """The downstream backbone (downstream/instance_segmentation/modeling/multimae/multimae_big_imcomplete.py, SURVEY 8f
+    row f4) with its sibling modules, imported unmodified through a stub package whose __path__ is that directory."""
+    global _ds_cache
+    if _ds_cache is not None:
+        return _ds_cache
+    if not available():
+        raise RuntimeError("reference checkout not present at %s" % REF_ROOT)
+    saved = {k: v for k, v in sys.modules.items() if k == "multimae" or k.startswith("multimae.")}
+    for k in saved:
+        del sys.modules[k]
+    pkg = types.ModuleType("multimae")
+    pkg.__path__ = [DSI_MM]
+    sys.modules["multimae"] = pkg
+    ns = types.SimpleNamespace(
+        zu=importlib.import_module("multimae.zorro_utils"),
+        ia=importlib.import_module("multimae.input_adapters"),
+        big=importlib.import_module("multimae.multimae_big_imcomplete"),
+    )
+    for k in [k for k in sys.modules if k == "multimae" or k.startswith("multimae.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+    _ds_cache = ns
+    return ns
+
+
+def build_downstream_backbone(ds, *, dim_tokens, depth, dim_head, heads, image_size, patch_size=16,
+                              channels=(("s1", 1), ("s2", 3), ("dem", 1))):
+    """ViTBaseline built the way ViTMAE() does (multimae_big_imcomplete.py:756-797), free sizes, no pretrained file."""
+    T = ds.zu.TokenTypes
+    ia = {d: ds.ia.PatchedInputAdapter(num_channels=c, stride_level=1, patch_size_full=patch_size, image_size=image_size)
+          for d, c in channels}
+    ia["fusion"] = ds.ia.FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=patch_size, image_size=image_size)
+    return ds.big.ViTBaseline(input_adapters=ia, output_adapters=None, num_fusion_tokens=(image_size // patch_size) ** 2,
+                              return_token_types=(T.S1, T.S2, T.DEM, T.FUSION), drop_path_rate=0.0,
+                              dim_tokens=dim_tokens, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4,
+                              norm_layer=ds.zu.LayerNorm, in_domains=[c[0] for c in channels], frozen_stages=11,
+                              pretrained="/nonexistent")

@@ -30,7 +30,8 @@ class Golden:
     def sub(self, prefix):
         """{name: tensor} of all arrays below `prefix/`."""
         pre = prefix.rstrip("/") + "/"
-        return {k[len(pre):]: torch.from_numpy(np.array(self.z[k])) for k in self.z.files if k.startswith(pre)}
+        return {k[len(pre):]: torch.from_numpy(np.array(self.z[k])) for k in self.z.files
+                if k.startswith(pre) and self.z[k].dtype.kind in "fiub"}
 
     def json(self, key):
         return json.loads(str(self.z[key]))
