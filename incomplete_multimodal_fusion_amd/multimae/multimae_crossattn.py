@@ -201,6 +201,83 @@ class MultiMAE(nn.Module):
         info['num_task_tokens'] = i
         return info
 
+    # ---- packed encoder shared by the pretraining forward and the downstream backbone ------------------------------------
+    def _encode(self, x, doms, mask_all, N, explicit, taps=()):
+        """Patch-embed the kept patches of modalities `doms`, then run the depth x (Block_Fusion + Block) stack on the
+        packed row space.  Returns (descriptors, xm, xf, pending residual deltas, tap list): the residual stream is
+        (xm, xf) PLUS the pending deltas, which the caller's next add+LayerNorm pass folds in.  `taps`: layer indices
+        after which the fusion tokens (B, P, D) are materialised (downstream feature taps)."""
+        B, _, H, W = x[doms[0]].shape
+        device = x[doms[0]].device
+        M, D, Hh, dh = len(doms), self.dim_tokens, self.heads, self.dim_head
+        ps = self.input_adapters[doms[0]].P_H
+        nh, nw = H // ps, W // ps
+        P = nh * nw
+        T = compute_dtype(self.fusion_tokens)
+        desc = ops.Descriptors(mask_all.contiguous(), B, M, P, N)
+        if explicit and self.check_masks:
+            desc.check()
+        BN, BP = B * N, B * P
+
+        # -- patch embedding of the kept patches: one gather kernel + one GEMM for all modalities --------------------------
+        Ks = [self.input_adapters[d].num_channels * ps * ps for d in doms]
+        koff = [sum(Ks[:i]) for i in range(M)]
+        onehot = sum(Ks)
+        Kcat = onehot + ((M + 7) // 8) * 8
+        pcat = ops.patchify_gather([x[d] for d in doms], koff, onehot, Kcat, ps, desc.tok_mod, desc.tok_patch, N, T)
+        wcat = torch.cat([self.input_adapters[d].proj.weight.reshape(D, -1) for d in doms] +
+                         [torch.stack([self.input_adapters[d].proj.bias for d in doms], dim=1),
+                          pcat.new_zeros(D, Kcat - onehot - M, dtype=torch.float32)], dim=1)
+        tok = linear(pcat, wcat, once=True)                                                   # (B*N, D), bias included
+        pe_table = torch.cat([interp_posemb(self.input_adapters[d].pos_emb, nh, nw) for d in doms], dim=0)
+        if pe_table.requires_grad:
+            xm = pe_table.index_select(0, desc.tok_pe.long())
+        else:
+            xm = ops.gather_rows(pe_table.detach().contiguous(), desc.tok_pe)      # (B*N, D) fp32
+        fus_pe = self.input_adapters['fusion'].posemb_rows()
+        xf = (self.fusion_tokens[0] + fus_pe).unsqueeze(0).expand(B, P, D).reshape(BP, D).contiguous()
+        me = self.mask_embedding[0].contiguous()                                   # (P, D) shared rows
+        # pending residual deltas (compute dtype): modality part / fusion part, as (tensor, row offset)
+        dm, dm_off, df, df_off = tok, 0, None, -1
+        tap_out = []
+
+        def one_delta(a, a_off, b, b_off):
+            """parts_add_ln takes ONE delta tensor; the two pending deltas are either the same tensor or one is None."""
+            if a is None:
+                return b, -1, b_off
+            if b is None:
+                return a, a_off, -1
+            assert a is b
+            return a, a_off, b_off
+
+        sw = self.side_stream_wgrad
+        for l in range(self.depth):
+            fus, blk = self.fus_blocks[l], self.blocks[l]
+            # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) ---------------------------
+            dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
+            (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
+                                              fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
+            # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
+            kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
+            a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
+            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
+            (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
+            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw, once=True)), fus.mlp[3].weight, side_wgrad=sw, once=True)          # (BP, D)
+            # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
+            (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
+                                           out_dtype=T)                                     # (BN+BP, D)
+            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
+            a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
+            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)
+            (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
+                                           out_dtype=T)
+            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw, once=True)), blk.mlp[3].weight, side_wgrad=sw, once=True)          # (BN+BP, D)
+            dm, dm_off, df, df_off = f, 0, f, BN
+            if l in taps:
+                tap_out.append((xf + f[BN:BN + BP].float()).reshape(B, P, D))
+
+        return desc, xm, xf, (dm, dm_off, df, df_off), tap_out
+
     # ---- the hot path ----------------------------------------------------------------------------------------------------
     def forward(self,
                 x: Union[Dict[str, torch.Tensor], torch.Tensor],
@@ -243,64 +320,17 @@ class MultiMAE(nn.Module):
             ids_keep = ids_shuffle[:, :N]
             mask_all = mask_full if self.per_sample_masks else mask_full[:1]      # row 0 drives the batch (:402-406)
             explicit = True
-        desc = ops.Descriptors(mask_all.contiguous(), B, M, P, N)
-        if explicit and self.check_masks:
-            desc.check()
+        desc, xm, xf, pend, _ = self._encode(x, doms, mask_all, N, explicit)
+        dm, dm_off, df, df_off = pend
         BN, BP = B * N, B * P
 
-        # -- patch embedding of the kept patches: one gather kernel + one GEMM for all modalities --------------------------
-        Ks = [self.input_adapters[d].num_channels * ps * ps for d in doms]
-        koff = [sum(Ks[:i]) for i in range(M)]
-        onehot = sum(Ks)
-        Kcat = onehot + ((M + 7) // 8) * 8
-        pcat = ops.patchify_gather([x[d] for d in doms], koff, onehot, Kcat, ps, desc.tok_mod, desc.tok_patch, N, T)
-        wcat = torch.cat([self.input_adapters[d].proj.weight.reshape(D, -1) for d in doms] +
-                         [torch.stack([self.input_adapters[d].proj.bias for d in doms], dim=1),
-                          pcat.new_zeros(D, Kcat - onehot - M, dtype=torch.float32)], dim=1)
-        tok = linear(pcat, wcat, once=True)                                                   # (B*N, D), bias included
-        pe_table = torch.cat([interp_posemb(self.input_adapters[d].pos_emb, nh, nw) for d in doms], dim=0)
-        if pe_table.requires_grad:
-            xm = pe_table.index_select(0, desc.tok_pe.long())
-        else:
-            xm = ops.gather_rows(pe_table.detach().contiguous(), desc.tok_pe)      # (B*N, D) fp32
-        fus_pe = self.input_adapters['fusion'].posemb_rows()
-        xf = (self.fusion_tokens[0] + fus_pe).unsqueeze(0).expand(B, P, D).reshape(BP, D).contiguous()
-        me = self.mask_embedding[0].contiguous()                                   # (P, D) shared rows
-        # pending residual deltas (compute dtype): modality part / fusion part, as (tensor, row offset)
-        dm, dm_off, df, df_off = tok, 0, None, -1
-
         def one_delta(a, a_off, b, b_off):
-            """parts_add_ln takes ONE delta tensor; the two pending deltas are either the same tensor or one is None."""
             if a is None:
                 return b, -1, b_off
             if b is None:
                 return a, a_off, -1
             assert a is b
             return a, a_off, b_off
-
-        sw = self.side_stream_wgrad
-        for l in range(self.depth):
-            fus, blk = self.fus_blocks[l], self.blocks[l]
-            # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) ---------------------------
-            dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
-            (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
-                                              fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
-            # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
-            kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
-            a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
-            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
-            (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
-            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw, once=True)), fus.mlp[3].weight, side_wgrad=sw, once=True)          # (BP, D)
-            # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
-            (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
-                                           out_dtype=T)                                     # (BN+BP, D)
-            qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
-            a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
-            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)
-            (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
-                                           out_dtype=T)
-            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw, once=True)), blk.mlp[3].weight, side_wgrad=sw, once=True)          # (BN+BP, D)
-            dm, dm_off, df, df_off = f, 0, f, BN
 
         # ---- final norm (:472) -------------------------------------------------------------------------------------------
         dl, o1, o2 = one_delta(dm, dm_off, df, df_off)

@@ -120,3 +120,23 @@ def test_install_as_multimae_resolves_driver_imports():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_downstream_backbone_state_dict_abi():
+    """ViTBaseline keeps the downstream reference's checkpoint keys (tests/golden/downstream.npz state, strict load)."""
+    from tests.conftest import Golden
+    from incomplete_multimodal_fusion_amd.multimae import FusionInputAdapter, PatchedInputAdapter, TokenTypes
+    from incomplete_multimodal_fusion_amd.multimae.multimae_big_imcomplete import ViTBaseline
+    g = Golden("downstream.npz")
+    cfg = g.json("config")
+    ia = {d: PatchedInputAdapter(num_channels=c, stride_level=1, patch_size_full=cfg["patch_size"], image_size=cfg["image_size"])
+          for d, c in cfg["channels"]}
+    ia["fusion"] = FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=cfg["patch_size"], image_size=cfg["image_size"])
+    m = ViTBaseline(input_adapters=ia, output_adapters=None, num_fusion_tokens=(cfg["image_size"] // cfg["patch_size"]) ** 2,
+                    return_token_types=(TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION),
+                    dim_tokens=cfg["dim_tokens"], depth=cfg["depth"], dim_head=cfg["dim_head"], heads=cfg["heads"],
+                    in_domains=[c[0] for c in cfg["channels"]], pretrained="/nonexistent")
+    state = g.sub("state")
+    missing, unexpected = torch.nn.Module.load_state_dict(m, state, strict=True)
+    assert not missing and not unexpected
+    assert m.flags == cfg["flags"]
