@@ -88,9 +88,10 @@ def pmc_traffic(kernel_substr):
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
     try:
         ks = json.load(open(path))["kernels"]
-        for name, v in ks.items():
-            if kernel_substr in name:
-                return round(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"])
+        cand = [v for name, v in ks.items() if kernel_substr in name]
+        if cand:                                            # several template instances: the one the step launches most
+            v = max(cand, key=lambda c: c["launches"] * (c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]))
+            return round(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"])
     except Exception:
         pass
     return None
