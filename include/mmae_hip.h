@@ -131,6 +131,14 @@ int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const float* out_2, 
 int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);
+/* Transposed bf16 copies of many 2-D weights in ONE launch (the data-gradient GEMMs of ops._Linear read W^T; torch did one
+ * `w.t().contiguous()` kernel per weight per step).  One 64x64 tile per row of `tiles`, 32 bytes each:
+ * {int64 src element offset of the tile, int64 dst element offset, int32 ld_src, int32 ld_dst, int32 rows, int32 cols}
+ * with rows, cols <= 64 and multiples of 8, all offsets multiples of 8 elements. */
+int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16, const void* tiles, int n_tiles, void* stream);
+/* out[i] = sum_s partials[s*n + i], fp32 accumulation in fixed order: reduction of the S bf16 partial products of a split-K
+ * weight-gradient GEMM (autograd of nn.Linear in the reference) into its fp32 destination.  n % 8 == 0. */
+int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* stream);
 /* L2 norm of a flat fp32 gradient buffer (deterministic two-stage sum); partial_ws: 2048 floats. */
 int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, float* out_norm, void* stream);
 

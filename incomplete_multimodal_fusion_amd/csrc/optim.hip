@@ -45,6 +45,56 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ p
     }
 }
 
+// Transposed bf16 shadows of the 2-D weights, all in one launch: the data-gradient GEMMs run dx = g @ W as
+// linear(g, W^T) (both operands contraction-contiguous), and W changes once per optimizer step.  One 64x64 tile per block;
+// `tiles` rows = {src element offset of the tile, dst element offset, ld_src, ld_dst, rows, cols} (rows/cols % 8 == 0).
+struct TrTile { long long src, dst; int ld_src, ld_dst, nr, nc; };
+static_assert(sizeof(TrTile) == 32, "TrTile layout is part of the C ABI (mmae_transpose_bf16_batched)");
+
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                                      const TrTile* __restrict__ tiles) {
+    __shared__ bf16 lds[64][72];                       // +8 pad: 144-byte rows keep the 16-byte row writes aligned
+    const TrTile t = tiles[blockIdx.x];
+    const int v = (threadIdx.x & 7) * 8, r = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = r + 32 * pass;
+        if (row < t.nr && v < t.nc)
+            *reinterpret_cast<uint4*>(&lds[row][v]) = *reinterpret_cast<const uint4*>(src + t.src + (long)row * t.ld_src + v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int col = r + 32 * pass;                 // source column = destination row
+        if (col < t.nc && v < t.nr) {
+            union { uint4 q; bf16 e[8]; } o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = lds[v + i][col];
+            *reinterpret_cast<uint4*>(dst + t.dst + (long)col * t.ld_dst + v) = o.q;
+        }
+    }
+}
+
+// out[i] = sum_s part[s*n + i]: fp32 reduction of the S bf16 partial products of a split-K weight-gradient GEMM, written
+// straight to its fp32 destination (the flat gradient buffer).  8 elements per lane, fixed summation order.
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const bf16* __restrict__ part, int S, long n, float* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+        union { uint4 q; bf16 e[8]; } v;
+        v.q = *reinterpret_cast<const uint4*>(part + (long)s * n + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+    }
+    f32x4 a, b;
+    a[0] = acc[0]; a[1] = acc[1]; a[2] = acc[2]; a[3] = acc[3];
+    b[0] = acc[4]; b[1] = acc[5]; b[2] = acc[6]; b[3] = acc[7];
+    *reinterpret_cast<f32x4*>(out + i) = a;
+    *reinterpret_cast<f32x4*>(out + i + 4) = b;
+}
+
 // sum of squares of a flat fp32 buffer -> out[0] (+= when accumulate): two-stage, deterministic
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
     __shared__ float red[4];
@@ -89,6 +139,25 @@ extern "C" int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void*
     if (n == 0) return MMAE_OK;
     hipLaunchKernelGGL(shadow_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
                        reinterpret_cast<bf16*>(shadow_bf16), n);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16, const void* tiles, int n_tiles, void* stream) {
+    if (n_tiles < 0 || !src_bf16 || !dst_bf16 || (n_tiles && !tiles)) return MMAE_ERR_ARG;
+    if (n_tiles == 0) return MMAE_OK;
+    hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16*>(src_bf16), reinterpret_cast<bf16*>(dst_bf16),
+                       reinterpret_cast<const TrTile*>(tiles));
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* stream) {
+    if (S < 1 || n < 0 || (n % 8) || !partials_bf16 || !out) return MMAE_ERR_ARG;
+    if (n == 0) return MMAE_OK;
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(partials_bf16), S, n, out);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -114,8 +114,13 @@ class GradAllReducer:
             b.expected = b.pending
 
     def _launch(self, b: _Bucket):
+        if self.engine is not None:
+            self.engine.flush()                              # batched copy of the small gradients into the flat buffer
         if self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # RCCL averages inside the collective (ncclAvg); gloo has no AVG, finish() scales there
+            self._avg_in_op = self.average and dist.get_backend(self.group) == "nccl"
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg_in_op else dist.ReduceOp.SUM,
+                                     group=self.group, async_op=True)
         else:
             b.work = True
 
@@ -125,10 +130,11 @@ class GradAllReducer:
             ops.join_wgrad_stream()                          # the gradient may come from the side-stream wgrad GEMM
         bi, off = self._where[p]
         b = self.buckets[bi]
-        view = b.flat[off:off + p.numel()].view_as(p)
-        if p.grad.data_ptr() != view.data_ptr():             # (engine: Linear gradients are already written in place)
-            view.copy_(p.grad)
-            p.grad = view                                    # the optimizer reads the reduced bucket in place
+        if self.engine is None:                              # (engine: its own hook ran first and queued the copy)
+            view = b.flat[off:off + p.numel()].view_as(p)
+            if p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view                                # the optimizer reads the reduced bucket in place
         b.pending -= 1
         if b.pending == 0 and b.work is None:
             self._launch(b)
@@ -136,6 +142,8 @@ class GradAllReducer:
     def finish(self):
         """Launch what backward could not complete (buckets holding never-used parameters on the first step), wait for
         every transfer on the current stream, average."""
+        if self.engine is not None:
+            self.engine.flush()
         for b in self.buckets:
             if b.work is None:
                 for p, off in zip(b.params, b.offsets):
@@ -147,7 +155,7 @@ class GradAllReducer:
         for b in self.buckets:
             if b.work is not True and b.work is not None:
                 b.work.wait()
-            if self.average and self.world > 1:
+            if self.average and self.world > 1 and not getattr(self, "_avg_in_op", False):
                 b.flat.mul_(1.0 / self.world)
         self._first = False
 

@@ -52,37 +52,99 @@ class FlatAdamW:
                 p._mmae_flat = (self, o)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.steps = 0
+        self._pending: Dict[int, torch.nn.Parameter] = {}
+        # transposed bf16 shadows (W^T for the data-gradient GEMMs): registered lazily by shadow_t_of(), each at its
+        # weight's own offset in a second bf16 buffer, refreshed by ONE batched-transpose launch after every update
+        self.shadow_t: Optional[torch.Tensor] = None
+        self._tr: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._tr_tiles: Optional[torch.Tensor] = None
         self.refresh_shadow()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.param_groups = [{"params": self.params, "lr": lr, "weight_decay": weight_decay, "lr_scale": 1.0}]
 
     # -- gradients -------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _on_grad(p: torch.nn.Parameter):
+    def _on_grad(self, p: torch.nn.Parameter):
+        # Gradients that were not written into the flat buffer by their producer (LayerNorm gammas, biases, embeddings,
+        # multi-use weights: a few hundred small tensors) are moved there in batches by flush(), not one copy kernel each.
         g = p.grad
         if g is not None and g.data_ptr() != p._mmae_grad.data_ptr():
-            p._mmae_grad.copy_(g)
+            self._pending[id(p)] = p
+
+    def flush(self):
+        """Move the pending gradients into the flat buffer (multi-tensor copy) and point .grad at their flat views.  Called
+        by grad_norm() / step() and by the DP reducer before it all-reduces a range of the buffer."""
+        if not self._pending:
+            return
+        ps = list(self._pending.values())
+        self._pending.clear()
+        with torch.no_grad():
+            torch._foreach_copy_([p._mmae_grad for p in ps], [p.grad for p in ps])
+        for p in ps:
             p.grad = p._mmae_grad
 
     def zero_grad(self, set_to_none: bool = True):
+        self._pending.clear()
         for p in self.params:
             p.grad = None
         self.grads.zero_()
 
     def grad_norm(self) -> torch.Tensor:
+        self.flush()
         call("mmae_grad_norm", self.n, ptr(self.grads), ptr(self._ws), ptr(self._norm), stream())
         return self._norm[0]
 
     # -- update ------------------------------------------------------------------------------------------------------
     def refresh_shadow(self):
         call("mmae_shadow_bf16", self.n, ptr(self.master), ptr(self.shadow), stream())
+        self._refresh_transposed()
+
+    def transposed_shadow(self, o0: int, R: int, C: int) -> Optional[torch.Tensor]:
+        """(C, R) bf16 view holding the transpose of the (R, C) weight block at flat offset o0; None if the block cannot
+        be registered (odd sizes, or it overlaps a differently shaped registered block)."""
+        key = (o0, R, C)
+        v = self._tr.get(key)
+        if v is not None:
+            return v
+        if R % 8 or C % 8 or o0 % 8:
+            return None
+        for (o, r, c) in self._tr:
+            if o < o0 + R * C and o0 < o + r * c:
+                return None
+        if self.shadow_t is None:
+            self.shadow_t = torch.empty(self.n, dtype=torch.bfloat16, device=self.master.device)
+        v = self.shadow_t[o0:o0 + R * C].view(C, R)
+        with torch.no_grad():
+            v.copy_(self.shadow[o0:o0 + R * C].view(R, C).t())
+        self._tr[key] = v
+        self._tr_tiles = None
+        return v
+
+    def _refresh_transposed(self):
+        if not self._tr:
+            return
+        if self._tr_tiles is None:
+            import numpy as np
+            rows = []
+            for (o0, R, C) in self._tr:
+                for r in range(0, R, 64):
+                    for c in range(0, C, 64):
+                        rows.append((o0 + r * C + c, o0 + c * R + r, C, R, min(64, R - r), min(64, C - c)))
+            tab = np.zeros(len(rows), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("ld_src", "<i4"), ("ld_dst", "<i4"),
+                                                      ("nr", "<i4"), ("nc", "<i4")]))
+            for i, t in enumerate(rows):
+                tab[i] = t
+            self._tr_tiles = torch.from_numpy(tab.view(np.uint8).reshape(-1, 32).copy()).to(self.master.device)
+        call("mmae_transpose_bf16_batched", ptr(self.shadow), ptr(self.shadow_t), ptr(self._tr_tiles),
+             self._tr_tiles.shape[0], stream())
 
     def step(self, grad_scale: float = 1.0):
         g = self.param_groups[0]
+        self.flush()
         self.steps += 1
         call("mmae_adamw_step", self.n, ptr(self.master), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              ptr(self.shadow), float(g["lr"]) * float(g.get("lr_scale", 1.0)), self.betas[0], self.betas[1], self.eps,
              float(g["weight_decay"]), self.steps, float(grad_scale), stream())
+        self._refresh_transposed()
 
     # -- checkpoint shell (moments per parameter name are produced by the caller from these flat views) ---------------
     def state_dict(self):
@@ -107,6 +169,19 @@ def shadow_of(ws, dtype) -> Optional[torch.Tensor]:
             return None
         o += w.numel()
     return eng.shadow[o0:o].view(sum(w.shape[0] for w in ws), ws[0].shape[1])
+
+
+def shadow_t_of(ws, dtype) -> Optional[torch.Tensor]:
+    """(K, sum N_i) bf16 transpose of the row-concatenated weights `ws` (kept fresh by the engine), or None."""
+    if dtype != torch.bfloat16 or not all(hasattr(w, "_mmae_flat") for w in ws):
+        return None
+    eng, o0 = ws[0]._mmae_flat
+    o = o0
+    for w in ws:
+        if w._mmae_flat[0] is not eng or w._mmae_flat[1] != o or w.numel() % _ALIGN or w.dim() != 2:
+            return None
+        o += w.numel()
+    return eng.transposed_shadow(o0, sum(w.shape[0] for w in ws), ws[0].shape[1])
 
 
 def grad_view_of(ws) -> Optional[torch.Tensor]:

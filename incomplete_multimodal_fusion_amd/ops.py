@@ -146,6 +146,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         # in-place flat gradient only for weights used ONCE per step: a second use would overwrite the first gradient
         ctx.gview = grad_view_of(ws) if (once and all(wi.dtype == torch.float32 for wi in ws)) else None
+        ctx.ws = ws
         ctx.meta = ([wi.shape[0] for wi in ws], [wi.dtype for wi in ws], bias is not None and bias.dtype, side)
         return y
 
@@ -160,7 +161,11 @@ class _Linear(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             # dx = g @ W as linear(g, W^T): both operands contraction-contiguous (the layout the forward GEMMs run in,
             # 10-30 % faster than the "nn" form at these shapes); transposing the small weight costs ~nothing
-            gx = torch.nn.functional.linear(g2, w.t().contiguous()).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            gx = None
+            if ctx.needs_input_grad[0]:
+                from .engine import shadow_t_of
+                wt = shadow_t_of(ctx.ws, w.dtype)            # engine: W^T is maintained by one batched launch per step
+                gx = torch.nn.functional.linear(g2, wt if wt is not None else w.t().contiguous()).reshape(x.shape)
             gws = [None] * len(sizes)
             if any(ctx.needs_input_grad[3:]):
                 # The weight gradient is off the critical path (nothing in this backward pass reads it) and MFMA-bound,
@@ -204,6 +209,10 @@ def _wgrad(g2, x2, gview):
     S = _split_k(rows, n_out, n_in)
     if S > 1:
         part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
+        if part.dtype == torch.bfloat16 and (n_out * n_in) % 8 == 0:
+            out = gview if gview is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device)
+            call("mmae_splitk_sum", S, n_out * n_in, ptr(part), ptr(out), stream())
+            return out
         return torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else part.sum(0, dtype=torch.float32)
     gw = torch.mm(g2.t(), x2)
     return gview.copy_(gw) if gview is not None else gw.float()
@@ -226,6 +235,7 @@ class _KvQ(torch.autograd.Function):
             kv = torch.nn.functional.linear(z, wkv_c)
             q = torch.nn.functional.linear(z[r0:r0 + n], wq_c)
         ctx.save_for_backward(z, wq_c, wkv_c)
+        ctx.wkv = wkv
         ctx.cfg = (r0, n, grad_view_of((wq,)) if wq.dtype == torch.float32 else None,
                    grad_view_of((wkv,)) if wkv.dtype == torch.float32 else None, wq.dtype, wkv.dtype)
         return kv, q
@@ -237,7 +247,9 @@ class _KvQ(torch.autograd.Function):
         gkv = gkv if gkv.is_contiguous() else gkv.contiguous()
         gq = gq if gq.is_contiguous() else gq.contiguous()
         with torch.autocast("cuda", enabled=False):
-            gz = torch.nn.functional.linear(gkv, wkv_c.t().contiguous())
+            from .engine import shadow_t_of
+            wt = shadow_t_of((ctx.wkv,), wkv_c.dtype)
+            gz = torch.nn.functional.linear(gkv, wt if wt is not None else wkv_c.t().contiguous())
             zs = gz[r0:r0 + n]
             torch.addmm(zs, gq, wq_c, out=zs)
             gwkv = _wgrad(gkv, z, gvkv)

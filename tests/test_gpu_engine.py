@@ -107,3 +107,43 @@ def test_training_reduces_loss(use_engine):
     losses = [float(step(x, task_masks=masks)["loss"]) for _ in range(40)]
     assert all(l == l for l in losses)
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+
+
+def test_transposed_shadow_and_splitk_sum():
+    """engine.shadow_t_of: W^T of (row-concatenated) weights kept fresh by ONE batched-transpose launch per update;
+    mmae_splitk_sum: fp32 reduction of bf16 split-K partials.  Both bit-exact against torch."""
+    from incomplete_multimodal_fusion_amd import ops
+    from incomplete_multimodal_fusion_amd._lib import call, ptr, stream
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW, shadow_of, shadow_t_of
+    torch.manual_seed(3)
+    shapes = [(512, 768), (1024, 768), (768, 2048), (85, 32), (72, 200), (256,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    opt = FlatAdamW(ps, lr=1e-2)
+    cat = shadow_t_of((ps[0], ps[1]), torch.bfloat16)            # [to_q | to_kv]-style concatenation
+    one = shadow_t_of((ps[2],), torch.bfloat16)
+    small = shadow_t_of((ps[4],), torch.bfloat16)               # ragged 64-tiles (72 x 200)
+    assert shadow_t_of((ps[3],), torch.bfloat16) is None        # 85 x 32: not 8-aligned -> torch fallback in ops
+    assert shadow_t_of((ps[0],), torch.bfloat16) is None        # overlaps the registered concatenation -> fallback
+    assert shadow_t_of((ps[2],), torch.float32) is None
+    for step in range(3):
+        assert torch.equal(cat, shadow_of((ps[0], ps[1]), torch.bfloat16).t())
+        assert torch.equal(one, ps[2].detach().to(torch.bfloat16).t())
+        assert torch.equal(small, ps[4].detach().to(torch.bfloat16).t())
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step()
+    # the data gradient of ops.linear goes through the transposed shadow
+    x = torch.randn(640, 768, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    y = ops.linear(x, [ps[0], ps[1]], once=True)
+    g = torch.randn_like(y)
+    y.backward(g)
+    want = (g.float() @ torch.cat([ps[0], ps[1]]).detach().to(torch.bfloat16).float())
+    close(x.grad, want, 1e-2, "dx through the transposed shadow")
+    for S, n_out, n_in in ((4, 768, 4096), (16, 768, 1024), (3, 40, 24)):
+        part = torch.randn(S, n_out, n_in, device=DEV).to(torch.bfloat16)
+        out = torch.empty(n_out, n_in, device=DEV)
+        call("mmae_splitk_sum", S, n_out * n_in, ptr(part), ptr(out), stream())
+        ref = torch.zeros(n_out, n_in, device=DEV)
+        for s in range(S):
+            ref += part[s].float()
+        assert torch.equal(out, ref)
