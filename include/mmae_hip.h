@@ -146,7 +146,8 @@ int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, float* out_no
 int mmae_masks_from_draws(int R, int M, int P, int N, const float* dirichlet, const float* noise,
                           const float* noise_all, long long* mask_all, long long* ids_keep, long long* ids_restore,
                           void* stream);
-/* int32 descriptor buffer; section offsets (15 entries, last = total ints) by mmae_descriptor_layout. */
+/* int32 descriptor buffer; section offsets (15 entries, last = total ints) by mmae_descriptor_layout (host pointer;
+ * returns the total, or MMAE_ERR_ARG). */
 long mmae_descriptor_layout(int B, int M, int P, int N, long* offsets15);
 int mmae_build_descriptors(int B, int R, int M, int P, int N, const long long* mask_all, int* desc, void* stream);
 

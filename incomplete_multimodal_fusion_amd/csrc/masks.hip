@@ -91,6 +91,7 @@ __host__ __device__ inline void layout(int B, int M, int P, int N, long* off) {
 }
 
 extern "C" long mmae_descriptor_layout(int B, int M, int P, int N, long* offsets15) {
+    if (!offsets15 || B < 0 || M < 0 || P < 0 || N < 0) return MMAE_ERR_ARG;
     layout(B, M, P, N, offsets15);
     return offsets15[14];
 }
