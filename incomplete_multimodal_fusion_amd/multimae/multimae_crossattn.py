@@ -262,7 +262,7 @@ class MultiMAE(nn.Module):
             a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
             o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
             (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
-            f = linear(ops.geglu(linear(y, fus.mlp[1].weight, side_wgrad=sw, once=True)), fus.mlp[3].weight, side_wgrad=sw, once=True)          # (BP, D)
+            f = ops.feedforward_geglu(y, fus.mlp[1].weight, fus.mlp[3].weight)                    # (BP, D)
             # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
             (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
                                            out_dtype=T)                                     # (BN+BP, D)
@@ -271,7 +271,7 @@ class MultiMAE(nn.Module):
             o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
                                            out_dtype=T)
-            f = linear(ops.geglu(linear(y, blk.mlp[1].weight, side_wgrad=sw, once=True)), blk.mlp[3].weight, side_wgrad=sw, once=True)          # (BN+BP, D)
+            f = ops.feedforward_geglu(y, blk.mlp[1].weight, blk.mlp[3].weight)                    # (BN+BP, D)
             dm, dm_off, df, df_off = f, 0, f, BN
             if l in taps:
                 tap_out.append((xf + f[BN:BN + BP].float()).reshape(B, P, D))

@@ -4,6 +4,7 @@ Every Function here launches hand-written gfx950 kernels through ctypes on torch
 projections between them are plain torch matmuls (hipBLASLt) chosen by the callers in multimae/.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -528,6 +529,85 @@ class _GELU(torch.autograd.Function):
 
 geglu = _GEGLU.apply
 gelu = _GELU.apply
+
+FF_CHUNKS = int(os.environ.get("MMAE_FF_CHUNKS", "1"))      # see _FeedForwardGEGLU: 2 was measured, no net gain
+
+
+def _row_chunks(rows: int, n: int):
+    """n nearly equal row ranges with 256-aligned boundaries (GEMM tiles stay whole)."""
+    if rows < 8192 or n <= 1:
+        return [(0, rows)]
+    n = min(n, rows // 4096)
+    step = (rows + n - 1) // n
+    step = (step + 255) // 256 * 256
+    return [(a, min(rows, a + step)) for a in range(0, rows, step)]
+
+
+class _FeedForwardGEGLU(torch.autograd.Function):
+    """f = GEGLU(y @ W1^T) @ W2^T (FeedForward[1:4], zorro_utils.py:115-128) as ONE node, optionally evaluated in
+    FF_CHUNKS row chunks (GEMM1 -> GEGLU -> GEMM2 back to back per chunk, so the (rows, 2*ffi) intermediate -- 1.3 GB at
+    the bench batch -- is consumed while its tail still sits in the 256 MB Infinity Cache).  Measured: in isolation
+    GEGLU drops 475 -> 359 us with two chunks (tools/probes/mall_chunk_probe.py); inside the step GEGLU gains 1.2 ms and
+    the half-size GEMMs lose 1.2 ms, so the default stays at one chunk.  The backward walks the same chunks:
+    dg = df @ W2 -> GEGLU' -> dy = dh @ W1; the two weight gradients are split-K GEMMs over all rows afterwards.
+    Both weights must be used once per step (see linear())."""
+
+    @staticmethod
+    def forward(ctx, y, w1, w2):
+        from .engine import grad_view_of, shadow_of
+        T = y.dtype
+        y = _c(y)
+
+        def cast(w):
+            c = shadow_of((w,), T)
+            return c if c is not None else (w if w.dtype == T else w.to(T))
+        w1c, w2c = cast(w1), cast(w2)
+        rows, F = y.shape[0], w2.shape[1]
+        assert w1.shape[0] == 2 * F and y.dim() == 2
+        h = torch.empty(rows, 2 * F, dtype=T, device=y.device)
+        g = torch.empty(rows, F, dtype=T, device=y.device)
+        f = torch.empty(rows, w2.shape[0], dtype=T, device=y.device)
+        with torch.autocast("cuda", enabled=False):
+            for a, b in _row_chunks(rows, FF_CHUNKS):
+                torch.mm(y[a:b], w1c.t(), out=h[a:b])
+                call("mmae_geglu_fwd", dt(T), b - a, F, ptr(h[a:b]), ptr(g[a:b]), stream())
+                torch.mm(g[a:b], w2c.t(), out=f[a:b])
+        ctx.save_for_backward(y, h, g, w1c, w2c)
+        f32 = w1.dtype == torch.float32 and w2.dtype == torch.float32
+        ctx.cfg = (w1, w2, grad_view_of((w1,)) if f32 else None, grad_view_of((w2,)) if f32 else None)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        from .engine import shadow_t_of
+        y, h, g, w1c, w2c = ctx.saved_tensors
+        w1, w2, gv1, gv2 = ctx.cfg
+        df = _c(df)
+        T = y.dtype
+        rows, F = y.shape[0], g.shape[1]
+        w1t = shadow_t_of((w1,), T)
+        w1t = w1t if w1t is not None else w1c.t().contiguous()          # (D, 2F)
+        w2t = shadow_t_of((w2,), T)
+        w2t = w2t if w2t is not None else w2c.t().contiguous()          # (F, D)
+        dh = torch.empty_like(h)
+        dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        with torch.autocast("cuda", enabled=False):
+            chunks = _row_chunks(rows, FF_CHUNKS)
+            dg = torch.empty(max(b - a for a, b in chunks), F, dtype=T, device=y.device)
+            for a, b in chunks:
+                torch.mm(df[a:b], w2t.t(), out=dg[:b - a])                # dg = df @ W2
+                call("mmae_geglu_bwd", dt(T), b - a, F, ptr(h[a:b]), ptr(dg), ptr(dh[a:b]), stream())
+                if dy is not None:
+                    torch.mm(dh[a:b], w1t.t(), out=dy[a:b])               # dy = dh @ W1
+            gw2 = _wgrad(df, g, gv2)
+            gw1 = _wgrad(dh, y, gv1)
+        return dy, gw1 if gw1.dtype == w1.dtype else gw1.to(w1.dtype), gw2 if gw2.dtype == w2.dtype else gw2.to(w2.dtype)
+
+
+def feedforward_geglu(y, w1, w2):
+    """y (rows, D) in the compute dtype -> GEGLU(y @ w1^T) @ w2^T.  w1 (2*ffi, D), w2 (D, ffi): fp32 masters, each used
+    once per optimizer step."""
+    return _FeedForwardGEGLU.apply(y, w1, w2)
 
 
 # ------------------------------------------------------------------------------------------------ gather rows
