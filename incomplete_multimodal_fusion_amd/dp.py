@@ -24,6 +24,7 @@ def init_distributed(backend: Optional[str] = None) -> bool:
     if world <= 1:
         return False
     if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL over xGMI needs it on this driver
         if backend is None:
             backend = os.environ.get("MMAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
