@@ -142,6 +142,19 @@ int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* 
 /* L2 norm of a flat fp32 gradient buffer (deterministic two-stage sum); partial_ws: 2048 floats. */
 int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, float* out_norm, void* stream);
 
+/* ---- input staging (PT/utils/multimodal_dfc2023.py:99-139 with :25-49) ---------------------------------
+ * raw (B, C, H*factor, W*factor) of in_dtype -> out (B, C, H, W) fp32.  `factor` = integer shrink (cv2.INTER_AREA = block
+ * mean; uint8 input rounds the mean like cv2).  kind SAR_DB: 10*log10(x+1e-7), clip [-25,0], NaN->0, then (x-mean)/std;
+ * AFFINE: nan_to_num then per-channel (x-mean[c])/std[c]; ZSCORE: nan_to_num then per-(sample, channel) tile
+ * (x - mean(x)) / sqrt(var(x) + 1e-6) (mean/std ignored, may be null).  mean/std: C host floats. */
+#define MMAE_STAGE_SAR_DB 0
+#define MMAE_STAGE_AFFINE 1
+#define MMAE_STAGE_ZSCORE 2
+#define MMAE_RAW_F32 0
+#define MMAE_RAW_U8 1
+int mmae_stage_tiles(int kind, int in_dtype, int B, int C, int H, int W, int factor, const void* raw, float* out,
+                     const float* mean, const float* stdv, void* stream);
+
 /* ---- mask bookkeeping (MM/multimae_crossattn.py:233-272 with injected draws; :402-447, :454-462, :489-493) ---------- */
 int mmae_masks_from_draws(int R, int M, int P, int N, const float* dirichlet, const float* noise,
                           const float* noise_all, long long* mask_all, long long* ids_keep, long long* ids_restore,
