@@ -131,22 +131,28 @@ __device__ __forceinline__ KeyPlan key_plan(int seg, int nseg, int klen_seg, int
 // Per-thread staging geometry: chunk i of this thread covers row (tid + NT*i) / CPR, 8 columns at ((tid + NT*i) % CPR)*8.
 // The element offset inside a tile is loop invariant; only the tile's first row (a wave-uniform scalar) changes.
 template <int DH, int NT> struct StageIdx {
-    long goff[Geo<DH, NT>::NCH];     // row * stride + col  (elements), relative to the tile's first row
-    int row[Geo<DH, NT>::NCH];
+    int boff[Geo<DH, NT>::NCH];      // (row * stride + col) * 2: byte offset relative to the tile's first row
     int loff[Geo<DH, NT>::NCH];      // LDS element offset
+    int row_bytes;                   // stride * 2
     __device__ __forceinline__ void init(int tid, long stride, int col0) {
+        row_bytes = (int)stride * 2;
 #pragma unroll
         for (int i = 0; i < Geo<DH, NT>::NCH; ++i) {
             const int c = tid + NT * i, r = c / Geo<DH>::CPR, dc = c % Geo<DH>::CPR;
-            row[i] = r; goff[i] = (long)r * stride + col0 + dc * 8; loff[i] = r * Geo<DH>::KP + dc * 8;
+            boff[i] = (r * (int)stride + col0 + dc * 8) * 2; loff[i] = r * Geo<DH>::KP + dc * 8;
         }
     }
 };
+// Rows >= n of the tile read as ZERO through the buffer descriptor's range check (raw buffer, num_records = n rows):
+// no per-row compare / exec mask / branch around the loads.  `base` (first row of the tile) and n are wave-uniform.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 template <int DH, int NT>
 __device__ __forceinline__ void tile_load2(const bf16* base, const StageIdx<DH, NT>& ix, int n,
                                            bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, n * ix.row_bytes, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < Geo<DH, NT>::NCH; ++i) reg[i] = ix.row[i] < n ? ld8(base + ix.goff[i]) : z8();
+    for (int i = 0; i < Geo<DH, NT>::NCH; ++i)
+        reg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ix.boff[i], 0, 0));
 }
 template <int DH, int NT>
 __device__ __forceinline__ void tile_store2(bf16* img, const StageIdx<DH, NT>& ix, const bf16x8 (&reg)[Geo<DH, NT>::NCH]) {
@@ -253,8 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
                     s[t4][r] = e;
                     rs += e;
                 }
-            rs = rows_sum(rs);
-            l = l * alpha + rs;
+            l = l * alpha + rs;                               // per-lane partial; the four key rows are summed after the loop
             m = m_new;
 #pragma unroll
             for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
                 const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
                 tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
             }
-            l += (float)kn;
+            l += 0.25f * (float)kn;                           // (the four lane rows are summed after the loop)
             f32x4 one4[4];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4)
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
             }
         }
     }
+    l = rows_sum(l);
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
         bf16* op = reinterpret_cast<bf16*>(p.o) + (qrow0 + myq) * p.o_stride + h * DH + 4 * g;

@@ -16,7 +16,10 @@ ap.add_argument("--variants", default="0")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")
+ap.add_argument("--lib", default=None, help="another build of libmmae_hip.so (A/B runs inside one gpurun call)")
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = "cuda"
 B, H, dh, P = a.B, a.H, a.dh, 256
 nm = [int(x) for x in a.split.split(",")]
