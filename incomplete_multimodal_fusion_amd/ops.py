@@ -64,10 +64,13 @@ def set_kernel_timer(t):
 class Segments:
     """Device-side segment descriptors for the masked attention: int32 (B, nseg) start rows and lengths."""
 
-    def __init__(self, start: torch.Tensor, length: torch.Tensor, max_rows: int):
+    def __init__(self, start: torch.Tensor, length: torch.Tensor, max_rows: int, covers_all: bool = True):
+        """covers_all: every row of the operand belongs to exactly one segment (true for the packed row space of the
+        model).  With False the attention outputs / gradients are zero-initialised so rows outside every segment read 0."""
         assert start.dtype == torch.int32 and length.dtype == torch.int32 and start.shape == length.shape
         self.start, self.length, self.max_rows = _c(start), _c(length), int(max_rows)
         self.B, self.nseg = start.shape
+        self.covers_all = bool(covers_all)
 
     @staticmethod
     def dense(B: int, n: int, device, nseg: int = 1, row0: int = 0):
@@ -282,8 +285,9 @@ class _MHA(torch.autograd.Function):
         kv = qt if same else kvt
         assert qt.dim() == 2 and qt.stride(1) == 1 and kv.dim() == 2 and kv.stride(1) == 1
         assert qt.dtype == kv.dtype
-        out = torch.empty(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
-        lse = torch.empty(H, qt.shape[0], dtype=torch.float32, device=qt.device)
+        new = torch.empty if qseg.covers_all else torch.zeros
+        out = new(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
+        lse = new(H, qt.shape[0], dtype=torch.float32, device=qt.device)
         assert kseg.max_rows // 64 + kseg.nseg <= 80 and qseg.max_rows // 64 + qseg.nseg <= 80, \
             "at most ~4.8k rows per sample in one attention call"
         es = qt.element_size()
@@ -318,8 +322,9 @@ class _MHA(torch.autograd.Function):
         # columns outside them (none for fused qkv / kv projections) must not exist.
         assert qt.shape[1] == (3 * I if same else I) and kv.shape[1] == (3 * I if same else 2 * I), \
             "attention operands must be exactly the fused projection outputs"
-        gq = torch.empty_like(qt)
-        gkv = gq if same else torch.empty_like(kv)
+        # every row of q / kv belongs to exactly one segment unless the Segments say otherwise (then: zero-filled)
+        gq = torch.empty_like(qt) if (qseg.covers_all and (not same or kseg.covers_all)) else torch.zeros_like(qt)
+        gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
         delta = torch.empty_like(lse)
         es = qt.element_size()
         call("mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
@@ -411,9 +416,10 @@ class _PartsAddLN(torch.autograd.Function):
                     # residual unchanged: hand back an alias so that the stream's gradient flows THROUGH this function
                     # (added inside the backward kernel) instead of being summed by a separate full-size autograd add
                     outs.append(x.view_as(x))
-            call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
-                 ctypes.c_void_p(y.data_ptr() + r0 * D * y.element_size()), ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2),
-                 eps2, ctypes.c_void_p(stats.data_ptr() + r0 * 16), stream())
+            if x.shape[0] > 0:                                  # (an empty part -- e.g. no kept token at all -- is legal)
+                call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
+                     ctypes.c_void_p(y.data_ptr() + r0 * D * y.element_size()), ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2),
+                     eps2, ctypes.c_void_p(stats.data_ptr() + r0 * 16), stream())
             ln_in.append(xn)
             r0 += x.shape[0]
         ctx.save_for_backward(g1, b1, g2, stats, *ln_in)
