@@ -171,3 +171,68 @@ def test_fuzz_masked_losses_and_patchify():
         img = ops.unpatchify(tok.to(DEV), B, C, Hh, Hh, ps).cpu()
         ref = tok.view(B, nh, nh, C, ps, ps).permute(0, 3, 1, 4, 2, 5).reshape(B, C, Hh, Hh)
         assert torch.equal(img, ref), case
+
+
+def test_fuzz_end_to_end_vs_oracle():
+    """Whole step (forward, all losses, every parameter gradient) in fp32 mode on random small architectures and random
+    shared masks, including dropped modalities and a single kept token."""
+    from tests.test_cabi_symbols import build_model
+    from tests.test_gpu_e2e import native_step
+    rng = random.Random(31)
+    for case in range(6):
+        torch.manual_seed(100 + case)
+        dh = rng.choice([32, 64]); heads = rng.choice([1, 2, 3]); dim = rng.choice([32, 48, 96])
+        nh = rng.choice([2, 3, 4]); img = 16 * nh; P = nh * nh
+        ddh = rng.choice([32, 64]); dheads = rng.choice([1, 2])
+        cfg = dict(dim_tokens=dim, depth=rng.choice([1, 2, 3]), dim_head=dh, heads=heads, image_size=img, patch_size=16,
+                   decoder_dim=ddh * dheads, decoder_depth=rng.choice([1, 2]), decoder_heads=dheads)
+        channels = (("s1", 1), ("s2", 3), ("dem", 1))
+        model = build_model(cfg, channels)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.requires_grad and (n.endswith("gamma") or "norm" in n and n.endswith("weight")):
+                    p.add_(0.2 * torch.randn_like(p))
+            model.mask_embedding.add_(0.05 * torch.randn_like(model.mask_embedding))
+        B = rng.randint(1, 3)
+        keep = [rng.randint(0, P) for _ in range(3)]
+        if rng.random() < 0.4:
+            keep[rng.randrange(3)] = 0                                  # a dropped modality
+        if sum(keep) == 0:
+            keep[1] = 1
+        N = sum(keep)
+        x = {d: torch.randn(B, c, img, img) for d, c in channels}
+        masks = {}
+        for (d, _), k in zip(channels, keep):
+            row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+            masks[d] = row[None].repeat(B, 1)
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("pos_emb") and not k.endswith("beta"))
+             for k, v in state.items()}
+        out_r, (tl_r, lc_r, loss_r) = O.train_step_loss(p, x, masks, N, heads, dheads, 16)
+        loss_r.backward()
+        model.to(DEV).train()
+        xd = {k: v.to(DEV) for k, v in x.items()}; md = {k: v.to(DEV) for k, v in masks.items()}
+        out, tl, lc, loss = native_step(model, xd, md, N, bool(case % 2), False)
+        tag = " case %d %s keep %s B %d" % (case, cfg, keep, B)
+        for d in O.DOMAINS:
+            pred = out[0][d].image() if hasattr(out[0][d], "image") else out[0][d]
+            close(pred, out_r[0][d], 1e-3, "pred " + d + tag)
+            close(tl[d], tl_r[d], 1e-3, "loss " + d + tag)
+        close(out[2], out_r[2], 1e-3, "pooled" + tag); close(out[4], out_r[4], 1e-3, "fusion" + tag)
+        close(lc, lc_r, 1e-3, "contra" + tag); close(loss, loss_r, 1e-3, "loss" + tag)
+        loss.backward()
+        bad = []
+        gscale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None and not torch.isnan(v.grad).any())
+        for n, prm in model.named_parameters():
+            ref = p[n].grad
+            if ref is None:
+                assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
+                continue
+            if torch.isnan(ref).any():                                   # reference 0/0 (a sample with nothing masked)
+                continue
+            # a gradient that is analytically zero (e.g. the pooling query of a modality with ONE kept token: softmax
+            # over one key) is rounding noise on both sides: judge it against the step's overall gradient scale
+            err = float((prm.grad.detach().cpu().double() - ref.double()).abs().max())
+            if err > 2e-3 * max(float(ref.abs().max()), 1e-4 * gscale):
+                bad.append("%s: err %.3e ref max %.3e%s" % (n, err, float(ref.abs().max()), tag))
+        assert not bad, bad[:6]
