@@ -106,9 +106,11 @@ class GradAllReducer:
             for p, off in zip(b.params, b.offsets):
                 self._where[p] = (bi, off)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        engine.ready_callbacks.append(self._on_grad)         # gradients the producers write in place bypass autograd
 
     # -- per step -----------------------------------------------------------------------------------------------------
     def prepare(self):
+        self._seen = set()
         for b in self.buckets:
             b.work = None
             b.pending = sum(1 for p in b.params if p not in self._unused)
@@ -129,6 +131,13 @@ class GradAllReducer:
         if p.grad is not None and p.grad.is_cuda:
             from . import ops
             ops.join_wgrad_stream()                          # the gradient may come from the side-stream wgrad GEMM
+        seen = getattr(self, "_seen", None)
+        if seen is not None:
+            # a gradient published in place (engine.grads_written_in_place) reports here directly; this torch also runs
+            # the post-accumulate hook for the `None` the producer then hands to autograd -- count each parameter once
+            if id(p) in seen:
+                return
+            seen.add(id(p))
         bi, off = self._where[p]
         b = self.buckets[bi]
         if self.engine is None:                              # (engine: its own hook ran first and queued the copy)

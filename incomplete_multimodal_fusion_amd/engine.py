@@ -53,6 +53,7 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.steps = 0
         self._pending: Dict[int, torch.nn.Parameter] = {}
+        self.ready_callbacks = []          # called with a parameter whose gradient was written in place (see below)
         # transposed bf16 shadows (W^T for the data-gradient GEMMs): registered lazily by shadow_t_of(), each at its
         # weight's own offset in a second bf16 buffer, refreshed by ONE batched-transpose launch after every update
         self.shadow_t: Optional[torch.Tensor] = None
@@ -182,6 +183,19 @@ def shadow_t_of(ws, dtype) -> Optional[torch.Tensor]:
             return None
         o += w.numel()
     return eng.transposed_shadow(o0, sum(w.shape[0] for w in ws), ws[0].shape[1])
+
+
+def grads_written_in_place(ws) -> None:
+    """The producer wrote the fp32 gradient of `ws` straight into the flat buffer (ops._wgrad with grad_view_of): publish
+    it WITHOUT going through autograd's AccumulateGrad -- a returned view would be cloned there and copied back at the
+    next flush (two extra passes over every large weight).  Sets .grad to the flat view and runs the ready callbacks
+    (the DP reducer's bucket accounting) that post-accumulate hooks would have run."""
+    for w in ws:
+        eng = w._mmae_flat[0]
+        eng._pending.pop(id(w), None)
+        w.grad = w._mmae_grad
+        for cb in eng.ready_callbacks:
+            cb(w)
 
 
 def grad_view_of(ws) -> Optional[torch.Tensor]:

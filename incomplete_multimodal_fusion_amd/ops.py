@@ -185,13 +185,17 @@ class _Linear(torch.autograd.Function):
                 with torch.cuda.stream(ss) if use_side else _NullCtx():
                     gw = _wgrad(g2, x2, ctx.gview)   # ctx.gview: flat fp32 gradient buffer of the optimizer engine (or None)
                     off = 0
-                    for i, n in enumerate(sizes):
+                    publish = ctx.gview is not None and all(ctx.needs_input_grad[3:])
+                    for i, n in enumerate([] if publish else sizes):
                         if ctx.needs_input_grad[3 + i]:
                             gi = gw[off:off + n]
                             gws[i] = gi if gi.dtype == wdt[i] else gi.to(wdt[i])
                             if use_side:
                                 gws[i].record_stream(main)
                         off += n
+                if publish:
+                    from .engine import grads_written_in_place
+                    grads_written_in_place(ctx.ws)           # .grad = flat view; autograd gets None (no clone, no copy back)
             gb = None
             if bdt is not False and ctx.needs_input_grad[1]:
                 gb = g2.sum(0, dtype=torch.float32)
@@ -239,7 +243,7 @@ class _KvQ(torch.autograd.Function):
             kv = torch.nn.functional.linear(z, wkv_c)
             q = torch.nn.functional.linear(z[r0:r0 + n], wq_c)
         ctx.save_for_backward(z, wq_c, wkv_c)
-        ctx.wkv = wkv
+        ctx.wkv, ctx.wq = wkv, wq
         ctx.cfg = (r0, n, grad_view_of((wq,)) if wq.dtype == torch.float32 else None,
                    grad_view_of((wkv,)) if wkv.dtype == torch.float32 else None, wq.dtype, wkv.dtype)
         return kv, q
@@ -258,6 +262,10 @@ class _KvQ(torch.autograd.Function):
             torch.addmm(zs, gq, wq_c, out=zs)
             gwkv = _wgrad(gkv, z, gvkv)
             gwq = _wgrad(gq, z[r0:r0 + n], gvq)
+        if gvq is not None and gvkv is not None:
+            from .engine import grads_written_in_place
+            grads_written_in_place((ctx.wq, ctx.wkv))
+            return gz, None, None, None, None
         return gz, None, None, gwq if gwq.dtype == dq_ else gwq.to(dq_), gwkv if gwkv.dtype == dkv_ else gwkv.to(dkv_)
 
 
@@ -607,6 +615,10 @@ class _FeedForwardGEGLU(torch.autograd.Function):
                     torch.mm(dh[a:b], w1t.t(), out=dy[a:b])               # dy = dh @ W1
             gw2 = _wgrad(df, g, gv2)
             gw1 = _wgrad(dh, y, gv1)
+        if gv1 is not None and gv2 is not None:
+            from .engine import grads_written_in_place
+            grads_written_in_place((w1, w2))
+            return dy, None, None
         return dy, gw1 if gw1.dtype == w1.dtype else gw1.to(w1.dtype), gw2 if gw2.dtype == w2.dtype else gw2.to(w2.dtype)
 
 
