@@ -81,6 +81,30 @@ def cpu_baseline(args):
                       (args.model, args.input_size, args.input_size, B, N, len(times), t)}
 
 
+def step_flops(args, M=3):
+    """Algorithmic FLOPs of one optimizer step per sample, SURVEY.md 8(d): MACs_fwd of the reference-dense formulation
+    (Block + Block_Fusion as written + pooling heads + patch embedding + decoders), FLOPs_step = 6 * MACs_fwd (forward 2x,
+    backward 4x, no recompute credit); and the same with Block_Fusion as executed here (K/V of every row once, query /
+    output / FF of the fusion slot only).  ViT-B defaults: 539.8 GF reference-dense (179.9 forward)."""
+    D = {"tiny": 192, "small": 384, "base": 768, "large": 1024}[args.model]
+    L = {"tiny": 12, "small": 12, "base": 12, "large": 24}[args.model]
+    h = {"tiny": 3}.get(args.model, 8)
+    I, ffi, Dd, Ld, p = 64 * h, int(D * 8 / 3), 256, 2, 16
+    P = (args.input_size // p) ** 2
+    N = args.num_encoded_tokens
+    S = N + P
+    C = [1, 3, 1]
+    block = L * (4 * S * D * I + 2 * S * S * I + 3 * S * D * ffi)
+    fus_dense = L * (4 * P * (M + 1) * D * I + 2 * P * (M + 1) ** 2 * I + 3 * P * D * ffi)
+    fus_exec = L * (2 * S * D * I + 2 * P * D * I + 2 * P * (M + 1) * I + 3 * P * D * ffi)
+    pool = (M + 1) * 2 * D * I + 2 * S * D * I + 2 * (M + 1) * S * I + 8 * (M + 1) * D * D
+    ctr = M * (2 * D * I + 8 * D * D) + 2 * N * D * I
+    embed = sum(P * c * p * p * D for c in C)
+    dec = sum(P * D * Dd + Ld * (4 * P * Dd * Dd + 2 * P * P * Dd + 8 * P * Dd * Dd) + P * Dd * c * p * p for c in C)
+    rest = pool + ctr + embed + dec
+    return 6.0 * (block + fus_dense + rest), 6.0 * (block + fus_exec + rest)
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the roofline kernel from the committed PMC summary of THIS command (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/r01_pmc_hbm.json) -- the counters
@@ -116,6 +140,9 @@ def main():
     ap.add_argument("--side-wgrad", type=int, default=0, help="1: weight-gradient GEMMs on a side stream (measured: no gain)")
     ap.add_argument("--tunable", type=int, default=1, help="1: torch TunableOp picks the hipBLASLt/rocBLAS solution per GEMM "
                     "shape (pre-tuned table in incomplete_multimodal_fusion_amd/tuned/, unseen shapes are tuned during warm-up)")
+    ap.add_argument("--staging", type=int, default=0, help="1: PCIe-inclusive mode -- every step takes a fresh RAW host batch "
+                    "(fp32 SAR, uint8 RGB, fp32 DSM) through staging.TileStager (pinned ring, async H2D + normalisation "
+                    "kernels overlapped with the previous step).  Default 0: inputs resident in HBM (the contract's `value`)")
     ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
     args = ap.parse_args()
 
@@ -160,6 +187,25 @@ def main():
     x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)
     torch.manual_seed(4321 + rank)
 
+    next_batch = None
+    if args.staging:
+        import numpy as np
+        from incomplete_multimodal_fusion_amd import staging
+        g = np.random.default_rng(1234 + rank)
+        n = args.input_size
+        raw = {'s1': g.gamma(2.0, 0.1, size=(args.batch, 1, n, n)).astype(np.float32),
+               's2': g.integers(0, 256, size=(args.batch, 3, n, n), dtype=np.uint8),
+               'dem': g.normal(5.0, 7.0, size=(args.batch, 1, n, n)).astype(np.float32)}
+        stager = staging.TileStager(device, image_size=n, slots=2)
+        stager.submit(raw)
+
+        def next_batch():
+            xb = stager.get()
+            stager.submit(raw)                   # the following batch: host copy + H2D + staging under this step
+            return xb
+        plain_step = step
+        step = lambda _x: plain_step(next_batch())
+
     prof = ops.KernelTimer("mmae_mha_fwd")
     prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
     for _ in range(args.warmup):
@@ -202,7 +248,7 @@ def main():
                                    "kept (Dirichlet alpha=1 masks per step), decoders 256/2/8, MSE+L1+0.3*DINO, fwd+bwd+AdamW"
                                    % (args.model, args.input_size, args.input_size, args.num_encoded_tokens,
                                       3 * (args.input_size // 16) ** 2),
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world, "inputs": "host, PCIe inclusive" if args.staging else "resident in HBM",
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
             # dominant hand-written kernel by total time (profiles/r01_kernel_stats.md): the fused residual-add +
             # double-LayerNorm backward, HBM-bound.  achieved = algorithmic bytes of the launch / its HIP-event time.
@@ -221,6 +267,12 @@ def main():
                          "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 512 * 2,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},
         }
+        dense, executed = step_flops(args)
+        # whole-step view: algorithmic FLOPs per sample x samples/s against the dense bf16 MFMA peak of the job
+        out["roofline_step"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TF * world,
+                                "achieved": round(value * dense / 1e12, 1), "frac": round(value * dense / 1e12 / (MFMA_BF16_PEAK_TF * world), 4),
+                                "flops_per_sample_reference_dense": round(dense), "flops_per_sample_executed": round(executed),
+                                "achieved_executed": round(value * executed / 1e12, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
