@@ -163,10 +163,13 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 // __launch_bounds__(.., 2): at most 256 registers per lane, so the compiler selects the VGPR form of the MFMAs -- with the
 // default budget it parks accumulators in AGPRs and pays ~80 v_accvgpr_read/write per tile around the softmax.
-template <int DH, int NW>
+// QB = 16-query blocks per wave: with QB = 2 a block covers 128 queries with the same 4 waves, so every K/V tile that is
+// fetched (L2/HBM) and every K/V fragment read from LDS feeds twice the MFMAs -- the kernel is bound by exactly those two
+// streams (K/V tiles are re-read once per query tile: 1.7 GB per launch at the bench shape), not by issue slots.
+template <int DH, int NW, int QB = 1>
 __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
     typedef Geo<DH, NW * 64> G;
-    constexpr int NT = NW * 64, BM = NW * 16;
+    constexpr int NT = NW * 64, BM = NW * 16 * QB;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * G::KP];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * G::KP];
     __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
@@ -188,20 +191,26 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
         }
         if (lane == 0) tl_cnt = n;
     }
-    const int myq = wave * 16 + lr;
-    const bool qvalid = myq < ts.n;
-    bf16x8 qf[G::KS];
-    {
-        const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq) * p.q_stride + h * DH + 8 * g;
+    int myq[QB]; bool qvalid[QB];
+    bf16x8 qf[QB][G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) qf[ks] = qvalid ? ld8(qp + 32 * ks) : z8();
+    for (int qb = 0; qb < QB; ++qb) {
+        myq[qb] = (wave * QB + qb) * 16 + lr;
+        qvalid[qb] = myq[qb] < ts.n;
+        const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq[qb]) * p.q_stride + h * DH + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) qf[qb][ks] = qvalid[qb] ? ld8(qp + 32 * ks) : z8();
     }
     __syncthreads();
     const int ntile = uni(tl_cnt);
-    float m = -INFINITY, l = 0.f;                             // m is kept in the scaled (log2) domain
-    f32x4 oacc[G::DT];
+    float m[QB], l[QB];                                       // m is kept in the scaled (log2) domain
+    f32x4 oacc[QB][G::DT];
 #pragma unroll
-    for (int dt = 0; dt < G::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = -INFINITY; l[qb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) oacc[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const bf16* kg = reinterpret_cast<const bf16*>(p.k);
     const bf16* vg = reinterpret_cast<const bf16*>(p.v);
@@ -229,51 +238,64 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
                 tile_load2<DH, NT>(kg + r1 * p.k_stride, ixk, n1, kreg);
                 tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
             }
-            f32x4 s[4];
+            f32x4 s[QB][4];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
-                s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks)
-                    s[t4] = mma16(ld8(kfrag + 16 * t4 * G::KP + 32 * ks), qf[ks], s[t4]);
+                for (int qb = 0; qb < QB; ++qb) s[qb][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const bf16x8 kfr = ld8(kfrag + 16 * t4 * G::KP + 32 * ks);        // one LDS read, QB products
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) s[qb][t4] = mma16(kfr, qf[qb][ks], s[qb][t4]);
+                }
             }
-            if (kn < 64) {                                    // ragged last tile of a segment: scalar branch
+            bf16x8 pb[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x4 (&sq)[4] = s[qb];
+                if (kn < 64) {                                // ragged last tile of a segment: scalar branch
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * t4 + 4 * g + r >= kn) sq[t4][r] = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(sq[0][0], sq[0][1]), fmaxf(sq[0][2], sq[0][3]));
+#pragma unroll
+                for (int t4 = 1; t4 < 4; ++t4) mx = fmaxf(mx, fmaxf(fmaxf(sq[t4][0], sq[t4][1]), fmaxf(sq[t4][2], sq[t4][3])));
+                mx = rows_max(mx);
+                const float m_new = fmaxf(m[qb], mx * c);     // c > 0: max(c*s) = c*max(s); every tile has a valid key
+                const float alpha = fast_exp2(m[qb] - m_new);
+                float rs = 0.f;
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * t4 + 4 * g + r >= kn) s[t4][r] = -INFINITY;
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = fast_exp2(__builtin_fmaf(sq[t4][r], c, -m_new));   // -inf -> 0
+                        sq[t4][r] = e;
+                        rs += e;
+                    }
+                l[qb] = l[qb] * alpha + rs;                   // per-lane partial; the four key rows are summed after the loop
+                m[qb] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt) oacc[qb][dt] *= alpha;
+                pb[qb][0] = pack8(sq[0], sq[1]);
+                pb[qb][1] = pack8(sq[2], sq[3]);
             }
-            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-            for (int t4 = 1; t4 < 4; ++t4) mx = fmaxf(mx, fmaxf(fmaxf(s[t4][0], s[t4][1]), fmaxf(s[t4][2], s[t4][3])));
-            mx = rows_max(mx);
-            const float m_new = fmaxf(m, mx * c);             // c > 0: max(c*s) = c*max(s); every tile has a valid key
-            const float alpha = fast_exp2(m - m_new);
-            float rs = 0.f;
+            for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
+                for (int dt = 0; dt < G::DT; ++dt) {
+                    const bf16x8 vfr = tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane);    // one transposed LDS read, QB products
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = fast_exp2(__builtin_fmaf(s[t4][r], c, -m_new));   // -inf -> 0
-                    s[t4][r] = e;
-                    rs += e;
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = mma16(vfr, pb[qb][ks2], oacc[qb][dt]);
                 }
-            l = l * alpha + rs;                               // per-lane partial; the four key rows are summed after the loop
-            m = m_new;
-#pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt) oacc[dt] *= alpha;
-#pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2) {
-                const bf16x8 pb = pack8(s[2 * ks2], s[2 * ks2 + 1]);
-#pragma unroll
-                for (int dt = 0; dt < G::DT; ++dt)
-                    oacc[dt] = mma16(tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane), pb, oacc[dt]);
-            }
         }
     } else {
         // fully masked rows (finite masked_fill in the reference): uniform attention over every key -> column sums of V
-        m = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) m[qb] = 0.f;
         for (int t = 0; t < ntile; ++t) {
             __syncthreads();
             tile_store2<DH, NT>(Vs, ixv, vreg);
@@ -283,7 +305,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
                 const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
                 tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
             }
-            l += 0.25f * (float)kn;                           // (the four lane rows are summed after the loop)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) l[qb] += 0.25f * (float)kn;   // (the four lane rows are summed after the loop)
             f32x4 one4[4];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4)
@@ -293,18 +316,24 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
             for (int ks2 = 0; ks2 < 2; ++ks2) {
                 const bf16x8 pb = pack8(one4[2 * ks2], one4[2 * ks2 + 1]);
 #pragma unroll
-                for (int dt = 0; dt < G::DT; ++dt)
-                    oacc[dt] = mma16(tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane), pb, oacc[dt]);
+                for (int dt = 0; dt < G::DT; ++dt) {
+                    const bf16x8 vfr = tr_frag(Vs, G::KP, 32 * ks2, 16 * dt, lane);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = mma16(vfr, pb, oacc[qb][dt]);
+                }
             }
         }
     }
-    l = rows_sum(l);
-    if (qvalid) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-        bf16* op = reinterpret_cast<bf16*>(p.o) + (qrow0 + myq) * p.o_stride + h * DH + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) st4(op + 16 * dt, oacc[dt] * inv);
-        if (g == 0) p.lse[(long)h * p.stat_stride + qrow0 + myq] = l > 0.f ? m * LN2 + __logf(l) : 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lq = rows_sum(l[qb]);
+        if (qvalid[qb]) {
+            const float inv = lq > 0.f ? 1.f / lq : 0.f;
+            bf16* op = reinterpret_cast<bf16*>(p.o) + (qrow0 + myq[qb]) * p.o_stride + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) st4(op + 16 * dt, oacc[qb][dt] * inv);
+            if (g == 0) p.lse[(long)h * p.stat_stride + qrow0 + myq[qb]] = lq > 0.f ? m[qb] * LN2 + __logf(lq) : 0.f;
+        }
     }
 }
 
@@ -313,10 +342,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bf16_fwd_kernel(MhaDesc p) {
 // ------------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 // No per-element masks: rows of a ragged tile beyond its length are ZERO in the LDS images, so a padded key has K = V = 0
 // and contributes K^T dS = 0 to dQ whatever its (finite) dS is.
-template <int DH>
+// QB = 16-query blocks per wave (see the forward kernel): 2 -> 128-query tiles, K/V tile fetches and fragment reads halve.
+template <int DH, int QB = 1>
 __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
     typedef Geo<DH> G;
-    constexpr int NT = 256;
+    constexpr int NT = 256, BM = 64 * QB;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * G::KP];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * G::KP];
     __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
@@ -326,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
     if (bs.b < 0) return;
     const int b = bs.b, h = bs.h;
     SegTab st; st.load(p, b, lane);
-    const TileSel ts = pick_tile([&](int s) { return st.ql(s); }, p.nseg, bs.t);
+    const TileSel ts = pick_tile<BM>([&](int s) { return st.ql(s); }, p.nseg, bs.t);
     if (ts.seg < 0) return;
     const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
     const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
@@ -339,33 +369,51 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
             }
         if (lane == 0) tl_cnt = n;
     }
-    const int myq = wave * 16 + lr;
-    const bool qvalid = myq < ts.n;
-    bf16x8 qf[G::KS], dof[G::KS];
-    float dpart = 0.f;
-    {
-        const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq) * p.q_stride + h * DH + 8 * g;
-        const bf16* dop = reinterpret_cast<const bf16*>(p.dout) + (qrow0 + myq) * p.do_stride + h * DH + 8 * g;
-        const bf16* op = reinterpret_cast<const bf16*>(p.o) + (qrow0 + myq) * p.o_stride + h * DH + 8 * g;
+    int myq[QB]; bool qvalid[QB];
+    bf16x8 qf[QB][G::KS], dof[QB][G::KS];
+    f32x4 neg_lse4[QB], neg_delta4[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        myq[qb] = (wave * QB + qb) * 16 + lr;
+        qvalid[qb] = myq[qb] < ts.n;
+        float dpart = 0.f;
+        const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq[qb]) * p.q_stride + h * DH + 8 * g;
+        const bf16* dop = reinterpret_cast<const bf16*>(p.dout) + (qrow0 + myq[qb]) * p.do_stride + h * DH + 8 * g;
+        const bf16* op = reinterpret_cast<const bf16*>(p.o) + (qrow0 + myq[qb]) * p.o_stride + h * DH + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            qf[ks] = qvalid ? ld8(qp + 32 * ks) : z8();
-            dof[ks] = qvalid ? ld8(dop + 32 * ks) : z8();
-            const bf16x8 of = qvalid ? ld8(op + 32 * ks) : z8();
+            qf[qb][ks] = qvalid[qb] ? ld8(qp + 32 * ks) : z8();
+            dof[qb][ks] = qvalid[qb] ? ld8(dop + 32 * ks) : z8();
+            const bf16x8 of = qvalid[qb] ? ld8(op + 32 * ks) : z8();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
+            for (int j = 0; j < 8; ++j) dpart += (float)dof[qb][ks][j] * (float)of[j];
         }
+        const float delta = rows_sum(dpart);
+        const float lse2 = (qvalid[qb] ? p.lse[(long)h * p.stat_stride + qrow0 + myq[qb]] : 0.f) * LOG2E;
+        if (qvalid[qb] && g == 0) p.delta[(long)h * p.stat_stride + qrow0 + myq[qb]] = delta;
+        neg_lse4[qb] = f32x4{-lse2, -lse2, -lse2, -lse2};
+        neg_delta4[qb] = f32x4{-delta, -delta, -delta, -delta};
     }
-    const float delta = rows_sum(dpart);
-    const float lse2 = (qvalid ? p.lse[(long)h * p.stat_stride + qrow0 + myq] : 0.f) * LOG2E;
-    if (qvalid && g == 0) p.delta[(long)h * p.stat_stride + qrow0 + myq] = delta;
     __syncthreads();
     const int ntile = uni(tl_cnt);
-    const float c = p.scale * LOG2E;
-
-    f32x4 dqacc[G::DT];
+    // Row constants as the INITIAL accumulators (the query, hence lse and delta, is fixed per lane): with Q pre-scaled by
+    // scale*log2(e) the score chain ends as S' = log2-domain score - lse2 and the dP chain as dP - delta, so per score only
+    // exp2 and one multiply remain (was fma, exp2, sub, mul, mul); the softmax scale is applied to dQ once at the end.
+    {
+        const float c = p.scale * LOG2E;
 #pragma unroll
-    for (int dt = 0; dt < G::DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+    }
+
+    f32x4 dqacc[QB][G::DT];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) dqacc[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16* kg = reinterpret_cast<const bf16*>(p.k);
     const bf16* vg = reinterpret_cast<const bf16*>(p.v);
     StageIdx<DH, NT> ixk, ixv;
@@ -389,38 +437,51 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
             tile_load2<DH, NT>(kg + r1 * p.k_stride, ixk, n1, kreg);
             tile_load2<DH, NT>(vg + r1 * p.v_stride, ixv, n1, vreg);
         }
-        f32x4 s[4], dp[4];
+        f32x4 s[QB][4], dp[QB][4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-            s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) { s[qb][t4] = neg_lse4[qb]; dp[qb][t4] = neg_delta4[qb]; }
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s[t4] = mma16(ld8(kfrag + 16 * t4 * G::KP + 32 * ks), qf[ks], s[t4]);
-                dp[t4] = mma16(ld8(vfrag + 16 * t4 * G::KP + 32 * ks), dof[ks], dp[t4]);
+                const bf16x8 kfr = ld8(kfrag + 16 * t4 * G::KP + 32 * ks);
+                const bf16x8 vfr = ld8(vfrag + 16 * t4 * G::KP + 32 * ks);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    s[qb][t4] = mma16(kfr, qf[qb][ks], s[qb][t4]);
+                    dp[qb][t4] = mma16(vfr, dof[qb][ks], dp[qb][t4]);
+                }
             }
         }
+        bf16x8 dsb[QB][2];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+        for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = fast_exp2(__builtin_fmaf(s[t4][r], c, -lse2));
-                s[t4][r] = pv * (dp[t4][r] - delta) * p.scale;       // dS^T (finite also for padded keys)
-            }
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            const bf16x8 dsb = pack8(s[2 * ks2], s[2 * ks2 + 1]);
-#pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
-                dqacc[dt] = mma16(tr_frag(Ks, G::KP, 32 * ks2, 16 * dt, lane), dsb, dqacc[dt]);
+                for (int r = 0; r < 4; ++r)
+                    s[qb][t4][r] = fast_exp2(s[qb][t4][r]) * dp[qb][t4][r];   // dS^T / scale (finite also for padded keys)
+            dsb[qb][0] = pack8(s[qb][0], s[qb][1]);
+            dsb[qb][1] = pack8(s[qb][2], s[qb][3]);
         }
-    }
-    if (qvalid) {
-        bf16* dqp = reinterpret_cast<bf16*>(p.dq) + (qrow0 + myq) * p.dq_stride + h * DH + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) st4(dqp + 16 * dt, dqacc[dt]);
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                const bf16x8 kt = tr_frag(Ks, G::KP, 32 * ks2, 16 * dt, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) dqacc[qb][dt] = mma16(kt, dsb[qb][ks2], dqacc[qb][dt]);
+            }
     }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+        if (qvalid[qb]) {
+            bf16* dqp = reinterpret_cast<bf16*>(p.dq) + (qrow0 + myq[qb]) * p.dq_stride + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) st4(dqp + 16 * dt, dqacc[qb][dt] * p.scale);
+        }
 }
+
 
 // ------------------------------------------------------------------------------------------------------ backward: dK, dV
 // No per-element masks either: a padded query row has Q = dO = 0 (zero-filled image) and lse = delta = 0, so P is finite
@@ -469,13 +530,19 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
             kf[ks] = kvalid ? ld8(kp_ + 32 * ks) : z8();
             vf[ks] = kvalid ? ld8(vp_ + 32 * ks) : z8();
         }
+        // K pre-scaled by scale*log2(e) (it only feeds the score product here); -lse2 / -delta of the tile's query rows are
+        // the initial accumulators of the S and dP chains (see the dQ kernel); the softmax scale goes onto dK at the end
+        const float c = p.scale * LOG2E;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[ks][j] = (bf16)((float)kf[ks][j] * c);
     }
     f32x4 dkacc[G::DT], dvacc[G::DT];
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
     const int ntile = uni(tl_cnt);
-    const float c = p.scale * LOG2E;
     const bf16* qg = reinterpret_cast<const bf16*>(p.q);
     const bf16* dog = reinterpret_cast<const bf16*>(p.dout);
     StageIdx<DH, NT> ixq, ixo;
@@ -493,8 +560,8 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
         tile_load2<DH, NT>(dog + row * p.do_stride, ixo, n, doreg);
         if (tid < 64) {
             const bool v = tid < n;
-            lreg = v ? lse_g[row + tid] * LOG2E : 0.f;
-            dreg = v ? delta_g[row + tid] : 0.f;
+            lreg = v ? -lse_g[row + tid] * LOG2E : 0.f;            // stored negated: they are accumulator seeds
+            dreg = v ? -delta_g[row + tid] : 0.f;
         }
     };
     if (ntile > 0) fetch(0);
@@ -507,26 +574,21 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
         const int mode = uni(tl_mode[t]);
         if (t + 1 < ntile) fetch(t + 1);
         f32x4 s[4], dp[4];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            s[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                s[qt] = mma16(ld8(qfrag + 16 * qt * G::KP + 32 * ks), kf[ks], s[qt]);
-                dp[qt] = mma16(ld8(dofrag + 16 * qt * G::KP + 32 * ks), vf[ks], dp[qt]);
-            }
-        }
         if (mode == 1) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
+                s[qt] = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);        // -lse2 of the four query rows
+                dp[qt] = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);     // -delta
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    s[qt] = mma16(ld8(qfrag + 16 * qt * G::KP + 32 * ks), kf[ks], s[qt]);
+                    dp[qt] = mma16(ld8(dofrag + 16 * qt * G::KP + 32 * ks), vf[ks], dp[qt]);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = fast_exp2(__builtin_fmaf(s[qt][r], c, -l4[r]));
+                    const float pv = fast_exp2(s[qt][r]);
                     s[qt][r] = pv;
-                    dp[qt][r] = pv * (dp[qt][r] - d4[r]) * p.scale;
+                    dp[qt][r] = pv * dp[qt][r];                                           // dS / scale
                 }
             }
         } else {                                                  // uniform (fully masked) query rows: P = 1/K, dS = 0
@@ -534,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
             for (int qt = 0; qt < 4; ++qt) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[qt][r] = fast_exp2(-l4[r]); dp[qt][r] = 0.f; }
+                for (int r = 0; r < 4; ++r) { s[qt][r] = fast_exp2(l4[r]); dp[qt][r] = 0.f; }
             }
         }
 #pragma unroll
@@ -552,20 +614,23 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
         bf16* dkp = reinterpret_cast<bf16*>(p.dk) + (krow0 + mykey) * p.dk_stride + h * DH + 4 * g;
         bf16* dvp = reinterpret_cast<bf16*>(p.dv) + (krow0 + mykey) * p.dv_stride + h * DH + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) { st4(dkp + 16 * dt, dkacc[dt]); st4(dvp + 16 * dt, dvacc[dt]); }
+        for (int dt = 0; dt < G::DT; ++dt) { st4(dkp + 16 * dt, dkacc[dt] * p.scale); st4(dvp + 16 * dt, dvacc[dt]); }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
-static int g_variant = 0;   // tuning hook: 8 = 8 waves (128 query rows) per block in the forward kernel
+static int g_variant = 0;   // tuning hook for tools/bench_attn.py: forward tiling (0 default, 1, 8: see mha_bf16_fwd)
 extern "C" int mmae_mha_set_variant(int v) { g_variant = v; return 0; }
 
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
-    if (head_dim == 64 && g_variant == 8) {
+    if (head_dim == 64 && g_variant == 0) {                  // default: 4 waves x 32 queries = 128-query tiles
+        MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
+        hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
+    } else if (head_dim == 64 && g_variant == 8) {           // 8 waves x 16 queries (measured: no gain over 4 x 16)
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
-    } else {
+    } else {                                                 // variant 1 (dh 64) / dh 32: 4 waves x 16 queries
         dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
         if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 4>), grid, dim3(256), 0, st, d);
         else hipLaunchKernelGGL((mha_bf16_fwd_kernel<32, 4>), grid, dim3(256), 0, st, d);
@@ -577,7 +642,10 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st) {
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, hipStream_t st) {
     if (max_q_tiles > MAXT || max_k_tiles > MAXT) return MMAE_ERR_ARG;
     d.max_tiles = max_q_tiles;
-    if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<64>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
+    if (head_dim == 64 && g_variant == 2) {                  // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
+        d.max_tiles = (max_q_tiles + 1) / 2 + d.nseg;
+        hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);
+    } else if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<64>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
     else hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<32>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     d.max_tiles = max_k_tiles;
