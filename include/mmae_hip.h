@@ -78,7 +78,7 @@ int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float*
                     const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1, float* dgamma2,
                     float* dbeta2, float* ws, int accumulate, void* stream);
 
-/* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j], exact erf GELU ---------------- */
+/* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j]; erf GELU, Phi to 1.5e-7 - */
 int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream);
 int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream);
 /* ---- GELU of Mlp (DSI-MM/zorro_utils.py:141-143, MM/multimae_utils.py:148-150) -------------------------------------- */
