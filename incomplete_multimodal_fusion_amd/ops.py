@@ -103,11 +103,13 @@ def _split_k(rows: int, n_out: int, n_in: int) -> int:
     fills the chip: largest power of two with tiles * S <= 256, S <= 32 (tools/probes/wgrad_splitk_probe.py: 1.3-3.2x)."""
     tiles = ((n_out + 255) // 256) * ((n_in + 255) // 256)
     s = 1
-    while s < 32 and tiles * s * 2 <= 256 and rows % (s * 2) == 0 and rows // (s * 2) >= 2048:
+    while s < _SPLITK_MAX and tiles * s * 2 <= _SPLITK_CAP and rows % (s * 2) == 0 and rows // (s * 2) >= 2048:
         s *= 2
     return s
 
 
+_SPLITK_CAP = int(os.environ.get("MMAE_SPLITK_CAP", "256"))     # workgroups the split aims at (256 CUs)
+_SPLITK_MAX = int(os.environ.get("MMAE_SPLITK_MAX", "32"))
 _WGRAD_STREAMS = {}
 WGRAD_STREAM_PRIORITY = int(__import__('os').environ.get('MMAE_WGRAD_PRIO', '-1'))   # high priority: own HW queue
 WGRAD_SIDE_STREAM = True     # weight-gradient GEMMs of single-use weights run on a side HIP stream (see _Linear.backward)
