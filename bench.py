@@ -1,11 +1,22 @@
 #!/usr/bin/env python
 """Headline benchmark: pretrain samples/s of the native fusion-token path, ViT-B / 3 modalities / 256x256 tiles.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one rank per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`: RANK / WORLD_SIZE / MASTER_* in the environment), or -- when WORLD_SIZE is absent -- this process starts
+them itself as a CHILD torch.distributed.run before it has made any GPU call (launch_ranks(); the reference does the
+same job with torch.distributed.launch + utils/dist.py:62-93), forwards rank 0's JSON line and exits with the child's code.
 
 A step = Dirichlet mask draw + patch embedding of the kept patches + 12 x (Block_Fusion + Zorro-masked Block) + final
 norm + pooling + 3 decoders + masked MSE/L1 + 3 DINO-style contrastive terms + backward + gradient all-reduce (N > 1) +
 AdamW, on synthetic tiles already resident in HBM (BASELINE.md / SURVEY.md 8d).  Prints ONE JSON line on rank 0.
+
+`value` is the resident-input rate of the headline configuration (batch-shared Dirichlet masks, C4 of SURVEY 8d).  At
+N = 1 the same invocation also times two secondary legs on the same model and reports them beside it (never as
+`value`): `pcie_inclusive` -- every step takes a fresh RAW host batch through staging.TileStager (SURVEY 8d's step
+includes the H2D leg) -- and `c3_per_sample_dropout` -- per-sample packed masks with random modality dropout
+(`sample_tasks_uniformly`), the variable-token-count configuration north_star describes.
 """
 import argparse
 import json
@@ -20,6 +31,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+PROFILE_ROUNDS = ("r02", "r01")   # newest committed rocprofv3 summaries first
+
+
+# ---------------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args, argv) -> int:
+    """Start `args.gpus` ranks of this script under torch.distributed.run as a child process and return its exit code.
+    Called only while this process is still GPU-free (nothing but `import torch` has run), so no process that has
+    initialised HIP is ever replaced or forked."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC (RCCL over xGMI on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def build(args, device):
@@ -37,9 +69,20 @@ def synthetic_tiles(B, size, device, seed):
             "dem": torch.randn(B, 1, size, size, generator=g).to(device)}
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
     """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this box's host cores: same model,
-    same step definition (fwd + losses + bwd + AdamW), fp32, a bounded sample of the workload."""
+    same step definition (fwd + losses + bwd + AdamW), fp32, a bounded sample of the workload (B = 8, >= 3
+    timed steps when the host manages them inside ~45 s)."""
     from oracle import mmae_oracle as O
     from incomplete_multimodal_fusion_amd.pretrain import get_model
     try:
@@ -73,10 +116,10 @@ def cpu_baseline(args):
         print("[cpu_baseline] step %d: %.2f s (%d threads)" % (it, dt_, cores), file=sys.stderr, flush=True)
         if it > 0 or dt_ > 20.0:                     # a slow host: keep the (warm-up) step as the sample and stop
             times.append(dt_)
-        if time.perf_counter() - t_begin > 30.0 and times:
+        if time.perf_counter() - t_begin > 45.0 and times:
             break
     t = sum(times) / len(times)
-    return {"value": round(B / t, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(B / t, 4), "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
             "sample": "%s 3-mod %dx%d, B=%d, N=%d, fp32, fwd+bwd+AdamW, %d timed step(s), %.2f s/step" %
                       (args.model, args.input_size, args.input_size, B, N, len(times), t)}
 
@@ -105,20 +148,122 @@ def step_flops(args, M=3):
     return 6.0 * (block + fus_dense + rest), 6.0 * (block + fus_exec + rest)
 
 
+def _profile_json(stem):
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, stem))
+        if os.path.isfile(path):
+            try:
+                return json.load(open(path)), rnd
+            except Exception:
+                pass
+    return None, None
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the roofline kernel from the committed PMC summary of THIS command (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/r01_pmc_hbm.json) -- the counters
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see profiles/rNN_pmc_hbm.json) -- the counters
     cannot be collected from inside the process.  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    js, _ = _profile_json("pmc_hbm")
     try:
-        ks = json.load(open(path))["kernels"]
-        cand = [v for name, v in ks.items() if kernel_substr in name]
+        cand = [v for name, v in js["kernels"].items() if kernel_substr in name]
         if cand:                                            # several template instances: the one the step launches most
             v = max(cand, key=lambda c: c["launches"] * (c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]))
             return round(v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"])
     except Exception:
         pass
     return None
+
+
+def mfma_busy():
+    """Step-level MFMA-busy % (the second half of BASELINE.json's metric) from the committed SQ counter summary of this
+    command (profiles/rNN_sq_step.json, tools/prof_summary.py); None when absent."""
+    js, rnd = _profile_json("sq_step")
+    try:
+        return {"pct": js["step"]["mfma_busy_pct"], "source": "profiles/%s_sq_step.json" % rnd}
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------- dry run
+def dry_main(args):
+    """Launcher rehearsal without a GPU (tests/test_bench_launch.py): same rendezvous, barrier / max-over-ranks timing and
+    JSON assembly as the real run, gloo backend, but the 'step' is a small torch CPU module through dp.GradAllReducer --
+    NOT the product path (which has no CPU form) and NOT a measurement: the line is labelled dry_run and carries no
+    roofline."""
+    import torch.distributed as dist
+    from incomplete_multimodal_fusion_amd import dp
+    os.environ.setdefault("MMAE_DIST_BACKEND", "gloo")
+    distributed = dp.init_distributed()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    assert world == args.gpus, "launched %d ranks for --gpus %d" % (world, args.gpus)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 64))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    red = dp.GradAllReducer(net.parameters(), bucket_bytes=32 << 10) if distributed else None
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 64, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if red is not None:
+            red.prepare()
+        loss = (net(x) - x).pow(2).mean()
+        loss.backward()
+        if red is not None:
+            red.finish()
+        opt.step()
+        return loss.detach()
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if distributed:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    wsum = torch.cat([p.detach().flatten() for p in net.parameters()]).double().sum().reshape(1)
+    wall = [torch.zeros_like(wsum) for _ in range(world)]
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_gather(wall, wsum)
+    else:
+        wall = [wsum]
+    if rank == 0:
+        dt = float(tmax.item())
+        print(json.dumps({"metric": "launcher_dry_run", "dry_run": True, "value": round(args.batch * world * args.steps / dt, 2),
+                          "unit": "rows/s (stand-in CPU module, not the product path)", "n_gpus": world, "ranks": world,
+                          "backend": dist.get_backend() if distributed else "none", "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "replicas_in_sync": bool(all(float(w) == float(wall[0]) for w in wall)),
+                          "loss": round(float(loss), 6)}), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------- the run
+def timed_region(step, x, steps, distributed, device):
+    """barrier + synchronize | K steps | synchronize + barrier; MAX over ranks (contract of the driver)."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step(x)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), losses
 
 
 def main():
@@ -132,19 +277,32 @@ def main():
     ap.add_argument("--num-encoded-tokens", dest="num_encoded_tokens", type=int, default=384)
     ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=128)
     ap.add_argument("--engine", type=int, default=1, help="1: flat-buffer fused AdamW + bf16 shadow weights (csrc/optim.hip); "
                     "0: torch.optim.AdamW(fused=True) on the fp32 parameters")
     ap.add_argument("--side-wgrad", type=int, default=0, help="1: weight-gradient GEMMs on a side stream (measured: no gain)")
     ap.add_argument("--tunable", type=int, default=1, help="1: torch TunableOp picks the hipBLASLt/rocBLAS solution per GEMM "
                     "shape (pre-tuned table in incomplete_multimodal_fusion_amd/tuned/, unseen shapes are tuned during warm-up)")
-    ap.add_argument("--staging", type=int, default=0, help="1: PCIe-inclusive mode -- every step takes a fresh RAW host batch "
-                    "(fp32 SAR, uint8 RGB, fp32 DSM) through staging.TileStager (pinned ring, async H2D + normalisation "
-                    "kernels overlapped with the previous step).  Default 0: inputs resident in HBM (the contract's `value`)")
+    ap.add_argument("--staging", type=int, default=0, help="1: the MAIN timed region runs in PCIe-inclusive mode (every step "
+                    "takes a fresh RAW host batch through staging.TileStager).  Default 0: inputs resident in HBM (the "
+                    "contract's `value`); the PCIe-inclusive rate is then timed as a secondary leg")
+    ap.add_argument("--per-sample-masks", dest="per_sample", action="store_true",
+                    help="main region: every sample draws its own mask row (packed variable-length segments)")
+    ap.add_argument("--dropout", action="store_true", help="main region: random modality dropout (sample_tasks_uniformly: a "
+                    "uniformly drawn non-empty modality subset per mask row, the others get no tokens)")
+    ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3; "
+                    "'auto' = both at N = 1 with default main settings, none otherwise; 'none'")
+    ap.add_argument("--clip-grad", dest="clip_grad", type=float, default=0.0, help="> 0: device-side global-norm clipping")
+    ap.add_argument("--dry-run", dest="dry_run", action="store_true", help="launcher rehearsal on CPU/gloo (see dry_main)")
     ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))           # nothing here has touched the GPU yet
+    if args.dry_run:
+        return dry_main(args)
 
     import torch.distributed as dist
     from incomplete_multimodal_fusion_amd import dp, ops
@@ -152,7 +310,7 @@ def main():
     distributed = dp.init_distributed()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "launched %d ranks for --gpus %d" % (world, args.gpus)
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)   # (% only matters for the
     torch.cuda.set_device(local)                                                          #  single-GPU gloo rehearsal)
     device = torch.device("cuda", local)
@@ -182,13 +340,14 @@ def main():
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
         reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
-    step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer,
-                        side_stream_wgrad=bool(args.side_wgrad))
+    model.per_sample_masks = bool(args.per_sample)
+    resident_step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer,
+                                 side_stream_wgrad=bool(args.side_wgrad), sample_tasks_uniformly=bool(args.dropout),
+                                 clip_grad=args.clip_grad if args.clip_grad > 0 else None)
     x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)
     torch.manual_seed(4321 + rank)
 
-    next_batch = None
-    if args.staging:
+    def make_staged_step():
         import numpy as np
         from incomplete_multimodal_fusion_amd import staging
         g = np.random.default_rng(1234 + rank)
@@ -199,37 +358,54 @@ def main():
         stager = staging.TileStager(device, image_size=n, slots=2)
         stager.submit(raw)
 
-        def next_batch():
+        def staged(_x):
             xb = stager.get()
             stager.submit(raw)                   # the following batch: host copy + H2D + staging under this step
-            return xb
-        plain_step = step
-        step = lambda _x: plain_step(next_batch())
+            return resident_step(xb)
+        return staged
+
+    step = make_staged_step() if args.staging else resident_step
 
     prof = ops.KernelTimer("mmae_mha_fwd")
     prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
     for _ in range(args.warmup):
         losses = step(x)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
     ops.set_kernel_timer([prof, prof_ln])
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step(x)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, losses = timed_region(step, x, args.steps, distributed, device)
     ops.set_kernel_timer(None)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
     loss_val = float(losses["loss"])
     assert loss_val == loss_val, "non-finite loss"
+
+    # ---- secondary legs (same model / optimizer state, continuing the run; never `value`) -----------------------------
+    default_main = not (args.staging or args.per_sample or args.dropout or args.fp32)
+    legs = ("pcie,c3" if (world == 1 and default_main) else "") if args.legs == "auto" else \
+        ("" if args.legs == "none" else args.legs)
+    legs = [l for l in legs.split(",") if l]
+    leg_out = {}
+    if "pcie" in legs and not args.staging:
+        st = make_staged_step()
+        for _ in range(2):
+            st(x)
+        d2, l2 = timed_region(st, x, args.steps, distributed, device)
+        leg_out["pcie_inclusive"] = {
+            "value": round(args.batch * world * args.steps / d2, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d2 / args.steps, 3),
+            "inputs": "fresh RAW host batch per step (fp32 SAR, uint8 RGB, fp32 DSM; 0.72 MB/sample): pageable->pinned ring, "
+                      "async H2D + normalisation kernels (csrc/staging.hip) overlapped with the previous step",
+            "loss": round(float(l2["loss"]), 4)}
+    if "c3" in legs:
+        model.per_sample_masks = True
+        resident_step.uniform = True
+        for _ in range(2):
+            resident_step(x)
+        d3, l3 = timed_region(resident_step, x, args.steps, distributed, device)
+        model.per_sample_masks = bool(args.per_sample)
+        resident_step.uniform = bool(args.dropout)
+        leg_out["c3_per_sample_dropout"] = {
+            "value": round(args.batch * world * args.steps / d3, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d3 / args.steps, 3),
+            "masks": "one Dirichlet draw PER SAMPLE over a uniformly drawn non-empty modality subset (sample_tasks_uniformly: "
+                     "each modality dropped w.p. 1/2, never all), N=%d kept tokens per sample in variable-length packed "
+                     "segments" % args.num_encoded_tokens,
+            "loss": round(float(l3["loss"]), 4)}
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -240,17 +416,20 @@ def main():
         ach = flops / n_launch / (avg_ms * 1e-3) / 1e12 if n_launch else 0.0
         ln_ms, ln_n, ln_bytes = prof_ln.summary()
         ln_gbs = ln_bytes / ln_n / (ln_ms * 1e-3) / 1e9 if ln_n else 0.0
+        mask_desc = ("per-sample" if args.per_sample else "batch-shared") + (" + modality dropout" if args.dropout else "")
         out = {
             "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
             "config": {"workload": "ViT-%s (D768/L12/h8x64) 3-modality (s1+s2+dem) %dx%d tiles, patch 16, N=%d of %d tokens "
-                                   "kept (Dirichlet alpha=1 masks per step), decoders 256/2/8, MSE+L1+0.3*DINO, fwd+bwd+AdamW"
+                                   "kept (%s Dirichlet alpha=1 masks per step), decoders 256/2/8, MSE+L1+0.3*DINO, fwd+bwd+AdamW"
                                    % (args.model, args.input_size, args.input_size, args.num_encoded_tokens,
-                                      3 * (args.input_size // 16) ** 2),
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world, "inputs": "host, PCIe inclusive" if args.staging else "resident in HBM",
+                                      3 * (args.input_size // 16) ** 2, mask_desc),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "inputs": "host, PCIe inclusive" if args.staging else "resident in HBM",
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
-            # dominant hand-written kernel by total time (profiles/r01_kernel_stats.md): the fused residual-add +
+            "ranks": world, "backend": (dist.get_backend() if distributed else "none"),
+            # dominant hand-written kernel by total time (profiles/rNN_kernel_stats.md): the fused residual-add +
             # double-LayerNorm backward, HBM-bound.  achieved = algorithmic bytes of the launch / its HIP-event time.
             "roofline": {"kernel": "add_ln_bwd_kernel<bf16,bf16,3,double,nobeta>" if not args.fp32 else "add_ln_bwd_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -262,20 +441,30 @@ def main():
             "roofline_attention": {"kernel": "mha_bf16_fwd_kernel<64, 4, 2>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
-                         "traffic": pmc_traffic("mha_bf16_fwd_kernel<64") if (not args.fp32 and args.batch == 256) else None,
+                         "traffic": pmc_traffic("mha_bf16_fwd_kernel") if (not args.fp32 and args.batch == 256) else None,
                          "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
                          "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 512 * 2,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},
         }
         dense, executed = step_flops(args)
-        # whole-step view: algorithmic FLOPs per sample x samples/s against the dense bf16 MFMA peak of the job
-        out["roofline_step"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TF * world,
-                                "achieved": round(value * dense / 1e12, 1), "frac": round(value * dense / 1e12 / (MFMA_BF16_PEAK_TF * world), 4),
-                                "flops_per_sample_reference_dense": round(dense), "flops_per_sample_executed": round(executed),
-                                "achieved_executed": round(value * executed / 1e12, 1)}
+        # whole-step view: FLOPs per sample x samples/s against the dense bf16 MFMA peak of the job.  `achieved`
+        # / `frac` count the FLOPs this implementation EXECUTES (fusion-slot shortcut of Block_Fusion); the reference-dense
+        # formulation SURVEY 8d defines is kept beside it as a labelled secondary figure.
+        peak = MFMA_BF16_PEAK_TF * world
+        out["roofline_step"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak,
+                                "achieved": round(value * executed / 1e12, 1), "frac": round(value * executed / 1e12 / peak, 4),
+                                "flops_per_sample_executed": round(executed),
+                                "flops_per_sample_reference_dense": round(dense),
+                                "achieved_reference_dense": round(value * dense / 1e12, 1),
+                                "frac_reference_dense": round(value * dense / 1e12 / peak, 4)}
+        mb = mfma_busy()
+        if mb is not None and not args.fp32 and args.batch == 256:
+            out["mfma_busy_pct"] = mb["pct"]
+            out["mfma_busy_source"] = mb["source"]
+        out.update(leg_out)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

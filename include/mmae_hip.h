@@ -114,6 +114,16 @@ int mmae_masked_loss_bwd(int pred_dtype, int pred_is_tokens, int kind, int B, in
                          const void* pred, const float* target, const long long* mask, const float* den,
                          const float* stats, const float* gloss, void* gpred, void* stream);
 
+/* ---- masked cross-entropy (MM/criterion.py:24-58; the `dnw` class-map modality of PT/pretrain_mmae_my.py:67-74) ---------
+ * pred: logits, image (B,C,H,W) fp32 or decoder tokens (B*P, C*patch^2) of pred_dtype; target (B,H,W) int64 class ids;
+ * per-pixel CE with label smoothing, masked / reduced exactly like mmae_masked_loss_* (no mean over C). */
+int mmae_masked_ce_loss_fwd(int pred_dtype, int pred_is_tokens, int B, int C, int H, int W, int patch, const void* pred,
+                            const long long* target, const long long* mask, float label_smoothing, float* partial_ws,
+                            float* den, float* stats, void* stream);
+int mmae_masked_ce_loss_bwd(int pred_dtype, int pred_is_tokens, int B, int C, int H, int W, int patch, const void* pred,
+                            const long long* target, const long long* mask, float label_smoothing, const float* den,
+                            const float* stats, const float* gloss, void* gpred, void* stream);
+
 /* ---- contrastive heads: dino_loss_func (MM/criterion.py:328-335), HardNegtive_loss (MM/criterion.py:233-268) -------- */
 int mmae_dino_loss_fwd(int B, int D, const float* student, const float* teacher, float student_temp,
                        float teacher_temp, float* row_loss_ws, float* loss, void* stream);
@@ -130,6 +140,16 @@ int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const float* out_2, 
  * (loss-scale / averaging); `shadow_bf16` (optional) receives bf16(p) -- the weights the next forward's GEMMs read. */
 int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* Device-side gradient clipping / step skipping (PT/utils/native_scaler.py:20-40: clip_grad -> clip_grad_norm_, skip_grad ->
+ * no optimizer step when norm >= skip_grad; torch GradScaler: no step on a non-finite gradient) without the host round trip.
+ * mmae_adamw_control reads the norm mmae_grad_norm left on the device and fills ctl4 (4 floats, zero-initialised once by the
+ * caller): [0] gradient multiplier = grad_scale * min(1, max_norm / (norm*|grad_scale| + 1e-6)) (max_norm 0: no clipping),
+ * [1] 1 when the step is skipped (norm non-finite, or skip_norm > 0 and norm >= skip_norm), [2] running count of skipped
+ * steps, [3] the unscaled norm.  mmae_adamw_step_ctl is mmae_adamw_step taking the multiplier / skip flag from ctl4 and
+ * bias-correcting with step - ctl4[2], i.e. exactly as if optimizer.step() had not been called for skipped steps. */
+int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, float* ctl4, void* stream);
+int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, const float* ctl4, void* stream);
 int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);
 /* Transposed bf16 copies of many 2-D weights in ONE launch (the data-gradient GEMMs of ops._Linear read W^T; torch did one
  * `w.t().contiguous()` kernel per weight per step).  One 64x64 tile per row of `tiles`, 32 bytes each:

@@ -7,8 +7,10 @@ args.start_epoch = epoch + 1.  Consumers of the 'model' entry: pretraining/infer
 downstream backbone (downstream/.../multimae_big_imcomplete.py:456-460).
 
 The 'model' entry is the module's own state_dict (reference key names / shapes, tested by
-tests/test_cabi_symbols.py).  The 'optimizer' entry is written in torch.optim.AdamW's state_dict layout even when the
-fused flat engine (engine.FlatAdamW) produced it, so either optimizer can resume from either file.
+tests/test_cabi_symbols.py).  The 'optimizer' entry is written in the layout the REFERENCE trainer's optimizer has
+(torch.optim.AdamW over two groups: the model's trainable parameters, then the loss balancer's; create_optimizer's dict
+path, utils/optim_factory.py:136-150) even when the fused flat engine (engine.FlatAdamW) produced it, so either optimizer
+can resume from either file (tests/test_checkpoint.py builds the reference-way optimizer and exchanges files with it).
 """
 import glob
 import os
@@ -23,41 +25,67 @@ def _is_main() -> bool:
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
 
-def optimizer_state_dict(optimizer, model) -> dict:
-    """torch.optim.AdamW-layout state for a torch optimizer or an engine.FlatAdamW over model.parameters()."""
+def _trainable(model):
+    """The reference's model parameter group: [p for n, p in model.named_parameters() if p.requires_grad]
+    (utils/optim_factory.py:136-141) -- the frozen sin-cos pos_emb Parameters are NOT in the optimizer."""
+    return [p for _, p in model.named_parameters() if p.requires_grad]
+
+
+def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: float = 1.0) -> dict:
+    """torch.optim.AdamW state_dict in the reference trainer's layout for a torch optimizer or an engine.FlatAdamW:
+    two parameter groups -- model (lr_scale 1) then loss balancer (lr_scale balancer_lr_scale; empty for
+    NoWeightingStrategy) -- indexed over the trainable parameters in named_parameters() order; state only for parameters
+    that have been stepped (utils/optim_factory.py:136-150, pretrain_mmae.py:351-352)."""
     if isinstance(optimizer, torch.optim.Optimizer):
         return optimizer.state_dict()
-    params = list(model.parameters())
+    params = _trainable(model)
     idx = {id(p): i for i, p in enumerate(params)}
+    skipped = optimizer.skipped_steps()
     state = {}
     for p in optimizer.params:
+        st = max(0, optimizer._pstep[id(p)] - skipped)
+        if st == 0 or id(p) not in idx:
+            continue                                       # never stepped: torch keeps no state for it
         o = optimizer.offsets[id(p)]
         sl = slice(o, o + p.numel())
-        state[idx[id(p)]] = {"step": torch.tensor(float(optimizer.steps)),
+        state[idx[id(p)]] = {"step": torch.tensor(float(st)),
                              "exp_avg": optimizer.exp_avg[sl].view_as(p).detach().clone(),
                              "exp_avg_sq": optimizer.exp_avg_sq[sl].view_as(p).detach().clone()}
     g = optimizer.param_groups[0]
-    group = {"lr": g["lr"], "betas": tuple(optimizer.betas), "eps": optimizer.eps, "weight_decay": g["weight_decay"],
-             "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-             "fused": None, "lr_scale": g.get("lr_scale", 1.0), "params": list(range(len(params)))}
-    return {"state": state, "param_groups": [group]}
+    common = {"lr": g["lr"], "betas": tuple(optimizer.betas), "eps": optimizer.eps, "weight_decay": g["weight_decay"],
+              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+              "fused": None, "decoupled_weight_decay": True}
+    nb = len([p for p in balancer.parameters() if p.requires_grad]) if balancer is not None else 0
+    groups = [dict(common, lr_scale=g.get("lr_scale", 1.0), params=list(range(len(params)))),
+              dict(common, lr_scale=balancer_lr_scale, params=list(range(len(params), len(params) + nb)))]
+    return {"state": state, "param_groups": groups}
 
 
 def load_optimizer_state_dict(optimizer, model, sd: dict):
+    """Accepts the reference layout (two groups over the trainable parameters) written by either optimizer."""
     if isinstance(optimizer, torch.optim.Optimizer):
         optimizer.load_state_dict(sd)
         return
-    params = list(model.parameters())
-    steps = 0
+    params = _trainable(model)
+    n_model = len(sd["param_groups"][0]["params"])
+    if n_model != len(params):
+        raise ValueError("optimizer state has %d model parameters, the model has %d trainable ones" % (n_model, len(params)))
+    steps = {}
+    optimizer.exp_avg.zero_(); optimizer.exp_avg_sq.zero_()
     for i, st in sd["state"].items():
-        p = params[int(i)]
+        i = int(i)
+        if i >= n_model:
+            continue                                       # balancer group: not held by the flat engine
+        p = params[i]
+        if tuple(st["exp_avg"].shape) != tuple(p.shape):
+            raise ValueError("optimizer state %d has shape %s, parameter has %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
         if id(p) not in optimizer.offsets:
-            continue
+            continue                                       # excluded from the engine (never receives a gradient)
         o = optimizer.offsets[id(p)]
         optimizer.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
         optimizer.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
-        steps = max(steps, int(float(st["step"])))
-    optimizer.steps = steps
+        steps[id(p)] = int(float(st["step"]))
+    optimizer.set_param_steps(steps)
     g = sd["param_groups"][0]
     optimizer.param_groups[0]["lr"] = g["lr"]
     optimizer.param_groups[0]["weight_decay"] = g["weight_decay"]
@@ -69,7 +97,7 @@ def save_model(output_dir: str, epoch: int, model, optimizer, args=None, loss_sc
     if not _is_main():
         return None
     os.makedirs(output_dir, exist_ok=True)
-    to_save = {"model": model.state_dict(), "optimizer": optimizer_state_dict(optimizer, model), "epoch": epoch,
+    to_save = {"model": model.state_dict(), "optimizer": optimizer_state_dict(optimizer, model, loss_balancer), "epoch": epoch,
                "scaler": loss_scaler.state_dict() if loss_scaler is not None else {}, "args": args}
     if loss_balancer is not None:
         to_save["loss_balancer"] = loss_balancer.state_dict()

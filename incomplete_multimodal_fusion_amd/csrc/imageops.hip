@@ -255,3 +255,146 @@ extern "C" int mmae_masked_loss_bwd(int pred_dtype, int pred_is_tokens, int kind
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
+
+// ------------------------------------------------------------------------------------------ masked cross-entropy loss
+// MaskedCrossEntropyLoss (pretraining/multimae/criterion.py:24-58; the `dnw` land-cover modality of the 4-modality driver,
+// pretrain_mmae_my.py:67-74): per-pixel F.cross_entropy over C classes (label smoothing eps), nearest-upsampled patch mask,
+// per-sample masked mean, nanmean over samples.  Same two stages as the pixel losses above (no division by C here);
+// pred is the (B,C,H,W) fp32 logit image or the decoder's token-major (B*P, C*ps*ps) output, target (B,H,W) int64.
+struct CEDesc {
+    const void* pred; const long long* tgt; const long long* mask;
+    float* partial; long rows; int P, C, H, W, ps; float smooth;
+};
+
+template <typename T, bool TOKENS>
+__device__ __forceinline__ f32x4 ce_logits4(const CEDesc& d, long r, int b, int c, int pix, int py, int px) {
+    const int ps2 = d.ps * d.ps;
+    if (TOKENS) return ld4<T>(reinterpret_cast<const T*>(d.pred) + r * ((long)d.C * ps2) + (long)c * ps2 + pix);
+    const int y = pix / d.ps, x = pix % d.ps;
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(d.pred) +
+                                            (((long)b * d.C + c) * d.H + py + y) * d.W + px + x);
+}
+
+template <typename T, bool TOKENS>
+__global__ __launch_bounds__(256) void masked_ce_partial_kernel(CEDesc d) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= d.rows) return;
+    if (d.mask && d.mask[r] == 0) { if (lane == 0) d.partial[r] = 0.f; return; }
+    const int b = (int)(r / d.P), patch = (int)(r % d.P);
+    const int nw = d.W / d.ps, py = (patch / nw) * d.ps, px = (patch % nw) * d.ps, ps2 = d.ps * d.ps;
+    float acc = 0.f;
+    for (int pix = 4 * lane; pix < ps2; pix += 256) {
+        const int y = pix / d.ps, x = pix % d.ps;
+        const long long* tp = d.tgt + ((long)b * d.H + py + y) * d.W + px + x;
+        f32x4 mx{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        for (int c = 0; c < d.C; ++c) {
+            const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], v[j]);
+        }
+        f32x4 se{0.f, 0.f, 0.f, 0.f}, sx{0.f, 0.f, 0.f, 0.f}, xt{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < d.C; ++c) {
+            const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                se[j] += __expf(v[j] - mx[j]);
+                sx[j] += v[j];
+                if ((long long)c == tp[j]) xt[j] = v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lse = mx[j] + __logf(se[j]);
+            acc += (1.f - d.smooth) * (lse - xt[j]) + d.smooth * (lse - sx[j] / (float)d.C);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) d.partial[r] = acc;
+}
+
+template <typename T, bool TOKENS>
+__global__ __launch_bounds__(256) void masked_ce_bwd_kernel(CEDesc d, const float* den, const float* stats,
+                                                            const float* gloss, void* gpred) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= d.rows) return;
+    const int b = (int)(r / d.P), patch = (int)(r % d.P);
+    const int nw = d.W / d.ps, py = (patch / nw) * d.ps, px = (patch % nw) * d.ps, ps2 = d.ps * d.ps;
+    const bool on = !d.mask || d.mask[r] != 0;
+    const float dn = den[b], nv = stats[1];
+    const float coef = (on && dn > 0.f && nv > 0.f) ? gloss[0] / (nv * dn) : 0.f;
+    for (int pix = 4 * lane; pix < ps2; pix += 256) {
+        const int y = pix / d.ps, x = pix % d.ps;
+        const long long* tp = d.tgt + ((long)b * d.H + py + y) * d.W + px + x;
+        f32x4 mx{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, se{0.f, 0.f, 0.f, 0.f};
+        if (coef != 0.f) {
+            for (int c = 0; c < d.C; ++c) {
+                const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], v[j]);
+            }
+            for (int c = 0; c < d.C; ++c) {
+                const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) se[j] += __expf(v[j] - mx[j]);
+            }
+        }
+        for (int c = 0; c < d.C; ++c) {
+            f32x4 g{0.f, 0.f, 0.f, 0.f};
+            if (coef != 0.f) {
+                const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    g[j] = coef * (__expf(v[j] - mx[j]) / se[j] - ((long long)c == tp[j] ? 1.f - d.smooth : 0.f) - d.smooth / (float)d.C);
+            }
+            if (TOKENS) st4<T>(reinterpret_cast<T*>(gpred) + r * ((long)d.C * ps2) + (long)c * ps2 + pix, g);
+            else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(gpred) + (((long)b * d.C + c) * d.H + py + y) * d.W + px + x) = g;
+        }
+    }
+}
+
+static int ce_check(int pred_dtype, int pred_is_tokens, int B, int C, int H, int W, int patch, float smooth) {
+    if (pred_dtype != MMAE_F32 && pred_dtype != MMAE_BF16) return MMAE_ERR_ARG;
+    if (!pred_is_tokens && pred_dtype != MMAE_F32) return MMAE_ERR_ARG;
+    if (B <= 0 || C <= 0 || patch <= 0 || (patch % 4) || (H % patch) || (W % patch)) return MMAE_ERR_ARG;
+    if (!(smooth >= 0.f && smooth <= 1.f)) return MMAE_ERR_ARG;
+    return MMAE_OK;
+}
+
+extern "C" int mmae_masked_ce_loss_fwd(int pred_dtype, int pred_is_tokens, int B, int C, int H, int W, int patch,
+                                       const void* pred, const long long* target, const long long* mask,
+                                       float label_smoothing, float* partial_ws, float* den, float* stats, void* stream) {
+    int rc = ce_check(pred_dtype, pred_is_tokens, B, C, H, W, patch, label_smoothing);
+    if (rc) return rc;
+    if (!pred || !target || !partial_ws || !den || !stats) return MMAE_ERR_ARG;
+    const int P = (H / patch) * (W / patch);
+    CEDesc d{pred, target, mask, partial_ws, (long)B * P, P, C, H, W, patch, label_smoothing};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(d.rows, 4)), blk(256);
+    if (!pred_is_tokens) hipLaunchKernelGGL((masked_ce_partial_kernel<float, false>), grid, blk, 0, st, d);
+    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_ce_partial_kernel<bf16, true>), grid, blk, 0, st, d);
+    else hipLaunchKernelGGL((masked_ce_partial_kernel<float, true>), grid, blk, 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(masked_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, mask, B, P, patch, den, stats);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_masked_ce_loss_bwd(int pred_dtype, int pred_is_tokens, int B, int C, int H, int W, int patch,
+                                       const void* pred, const long long* target, const long long* mask,
+                                       float label_smoothing, const float* den, const float* stats, const float* gloss,
+                                       void* gpred, void* stream) {
+    int rc = ce_check(pred_dtype, pred_is_tokens, B, C, H, W, patch, label_smoothing);
+    if (rc) return rc;
+    if (!pred || !target || !den || !stats || !gloss || !gpred) return MMAE_ERR_ARG;
+    const int P = (H / patch) * (W / patch);
+    CEDesc d{pred, target, mask, nullptr, (long)B * P, P, C, H, W, patch, label_smoothing};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(d.rows, 4)), blk(256);
+    if (!pred_is_tokens) hipLaunchKernelGGL((masked_ce_bwd_kernel<float, false>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_ce_bwd_kernel<bf16, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else hipLaunchKernelGGL((masked_ce_bwd_kernel<float, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}

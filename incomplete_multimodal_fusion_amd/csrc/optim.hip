@@ -9,10 +9,35 @@
 #include "common.hpp"
 #include "mmae_hip.h"
 
+// Device-side step control (native_scaler.py:20-40 without the host round trip of `norm >= skip_grad` / GradScaler's
+// found-inf check): ctl[0] = multiplier applied to every gradient element (grad_scale x clip coefficient), ctl[1] = 1 when
+// this step must not be taken, ctl[2] = number of steps skipped so far (the bias correction uses step - ctl[2], exactly as if
+// optimizer.step() had not been called), ctl[3] = the unscaled gradient norm.
+__global__ void adamw_control_kernel(const float* __restrict__ norm, float max_norm, float skip_norm, float grad_scale,
+                                     float* __restrict__ ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float nrm = norm[0] * fabsf(grad_scale);
+    const bool finite = (nrm == nrm) && (nrm <= 3.0e38f);
+    const bool skip = !finite || (skip_norm > 0.f && nrm >= skip_norm);
+    float coef = 1.f;
+    if (max_norm > 0.f) { coef = max_norm / (nrm + 1e-6f); coef = coef > 1.f ? 1.f : coef; }   // torch clip_grad_norm_
+    ctl[0] = skip ? 0.f : grad_scale * coef;
+    ctl[1] = skip ? 1.f : 0.f;
+    ctl[2] = ctl[2] + (skip ? 1.f : 0.f);
+    ctl[3] = nrm;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow, long n, float lr,
-                                                    float b1, float b2, float eps, float wd, float inv_bc1,
-                                                    float inv_sqrt_bc2, float grad_scale) {
+                                                    float b1, float b2, float eps, float wd, int step, float grad_scale,
+                                                    const float* __restrict__ ctl) {
+    if (ctl) {
+        if (ctl[1] != 0.f) return;                      // skipped step: weights, moments and shadow stay as they are
+        grad_scale = ctl[0];
+        step -= (int)ctl[2];
+    }
+    const float inv_bc1 = 1.f / (1.f - powf(b1, (float)step));
+    const float inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, (float)step));
     const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = i0; i < n; i += stride) {
@@ -121,17 +146,37 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restri
 
 static int grid_for(long n) { long b = (n / 4 + 255) / 256; if (b > 2048) b = 2048; if (b < 1) b = 1; return (int)b; }
 
+static int adamw_launch(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, const float* ctl,
+                        void* stream) {
+    if (n < 0 || (n % 4) || !p || !g || !m || !v || step < 1) return MMAE_ERR_ARG;
+    if (n == 0) return MMAE_OK;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
+                       reinterpret_cast<bf16*>(shadow_bf16), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ctl);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
 extern "C" int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                                void* stream) {
-    if (n < 0 || (n % 4) || !p || !g || !m || !v || step < 1) return MMAE_ERR_ARG;
-    if (n == 0) return MMAE_OK;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
-                       reinterpret_cast<bf16*>(shadow_bf16), n, lr, beta1, beta2, eps, weight_decay, 1.f / bc1,
-                       1.f / sqrtf(bc2), grad_scale);
+    return adamw_launch(n, p, g, m, v, shadow_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
+}
+
+extern "C" int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, float* ctl4,
+                                  void* stream) {
+    if (!grad_norm || !ctl4 || max_norm < 0.f || skip_norm < 0.f) return MMAE_ERR_ARG;
+    hipLaunchKernelGGL(adamw_control_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), grad_norm, max_norm,
+                       skip_norm, grad_scale, ctl4);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
+}
+
+extern "C" int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, const float* ctl4,
+                                   void* stream) {
+    if (!ctl4) return MMAE_ERR_ARG;
+    return adamw_launch(n, p, g, m, v, shadow_bf16, lr, beta1, beta2, eps, weight_decay, step, 1.f, ctl4, stream);
 }
 
 extern "C" int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream) {

@@ -7,8 +7,16 @@ the hot path is the gradient all-reduce; samples are independent.
 Design for MI355X: few LARGE buckets (default 128 MiB: xGMI is point-to-point, 7 links per GPU, so per-collective
 latency is paid per bucket while bandwidth is per link), filled in reverse registration order = the order backward
 produces gradients, launched from post-accumulate-grad hooks as soon as a bucket is complete so that the transfer runs on
-RCCL's stream underneath the remaining backward kernels.  Parameters that never receive a gradient (the reference needs
-find_unused_parameters for 7 of them) are detected on the first step and then excluded statically -- no graph walk.
+RCCL's stream underneath the remaining backward kernels.  Buckets are launched strictly IN ORDER (bucket k only after
+0..k-1), so every rank issues the same sequence of collectives whatever the local arrival order of gradients.
+
+Unused parameters.  static_unused=True (pretraining: the same 7 parameters never receive a gradient on any rank or step;
+the reference needs find_unused_parameters for them): they are detected on the first step and then no longer waited for --
+no graph walk; if one of them later DOES receive a gradient the step raises instead of silently reducing a stale bucket.
+static_unused=False (downstream fine-tuning, where ViTBaseline draws a random modality subset per forward and rank): every
+parameter is expected every step, incomplete buckets are sent by finish() with zeros for the absent gradients, and a tiny
+MAX all-reduce of the per-parameter "has gradient" flags gives every rank the same set of updated parameters -- what DDP's
+find_unused_parameters=True does with its local_used_map.
 """
 import os
 from typing import Iterable, List, Optional
@@ -47,10 +55,12 @@ class _Bucket:
 
 class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
-                 average: bool = True, engine=None):
+                 average: bool = True, engine=None, static_unused: bool = True):
         """engine: an engine.FlatAdamW whose flat gradient buffer is all-reduced in place (buckets = contiguous ranges of
         it, no staging copies); without it the reducer owns its bucket buffers."""
         self.engine = engine
+        self.static_unused = bool(static_unused)
+        self._next = 0
         if engine is not None:
             self._init_flat(engine, bucket_bytes, group, average)
             return
@@ -111,6 +121,7 @@ class GradAllReducer:
     # -- per step -----------------------------------------------------------------------------------------------------
     def prepare(self):
         self._seen = set()
+        self._next = 0
         for b in self.buckets:
             b.work = None
             b.pending = sum(1 for p in b.params if p not in self._unused)
@@ -127,6 +138,15 @@ class GradAllReducer:
         else:
             b.work = True
 
+    def _launch_ready(self):
+        """Send every complete bucket at the head of the queue (strict order: same collective sequence on all ranks)."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.pending != 0:                               # incomplete: it and everything behind it wait
+                break
+            self._launch(b)
+            self._next += 1
+
     def _on_grad(self, p: torch.nn.Parameter):
         if p.grad is not None and p.grad.is_cuda:
             from . import ops
@@ -140,33 +160,50 @@ class GradAllReducer:
             seen.add(id(p))
         bi, off = self._where[p]
         b = self.buckets[bi]
+        if p in self._unused:
+            raise RuntimeError(
+                "GradAllReducer(static_unused=True): a parameter marked unused on the first step received a gradient "
+                "later (shape %s).  Its bucket may already be in flight without it.  Construct the reducer with "
+                "static_unused=False for models whose set of used parameters varies between steps or ranks." %
+                (tuple(p.shape),))
         if self.engine is None:                              # (engine: its own hook ran first and queued the copy)
             view = b.flat[off:off + p.numel()].view_as(p)
             if p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view                                # the optimizer reads the reduced bucket in place
         b.pending -= 1
-        if b.pending == 0 and b.work is None:
-            self._launch(b)
+        self._launch_ready()
 
     def finish(self):
-        """Launch what backward could not complete (buckets holding never-used parameters on the first step), wait for
-        every transfer on the current stream, average."""
+        """Send what backward could not complete (buckets holding parameters without a gradient), in order; wait for every
+        transfer on the current stream; average.  With static_unused=False also agree on the set of parameters that got a
+        gradient on ANY rank and hand those their (averaged) gradient on every rank."""
         if self.engine is not None:
             self.engine.flush()
-        for b in self.buckets:
-            if b.work is None:
-                for p, off in zip(b.params, b.offsets):
-                    if p.grad is None or p.grad.data_ptr() != b.flat[off:off + 1].data_ptr():
-                        b.flat[off:off + p.numel()].zero_()
-                        if self._first:
-                            self._unused.add(p)
-                self._launch(b)
+        for b in self.buckets[self._next:]:
+            for p, off in zip(b.params, b.offsets):
+                if p.grad is None or p.grad.data_ptr() != b.flat[off:off + 1].data_ptr():
+                    b.flat[off:off + p.numel()].zero_()      # absent gradient: this rank contributes zeros
+                    if self._first and self.static_unused:
+                        self._unused.add(p)
+            self._launch(b)
+        self._next = len(self.buckets)
+        used = None
+        if not self.static_unused and self.world > 1:
+            flags = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
+                                 device=self.buckets[0].flat.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            used = flags.tolist()                            # host sync, like DDP's local_used_map copy
         for b in self.buckets:
             if b.work is not True and b.work is not None:
                 b.work.wait()
             if self.average and self.world > 1 and not getattr(self, "_avg_in_op", False):
                 b.flat.mul_(1.0 / self.world)
+        if used is not None:
+            for p, u in zip(self.params, used):
+                if u and p.grad is None:                     # used on another rank: take part in the update here too
+                    bi, off = self._where[p]
+                    p.grad = self.buckets[bi].flat[off:off + p.numel()].view_as(p)
         self._first = False
 
     def unused_parameters(self):

@@ -8,6 +8,12 @@ state_dict()/load_state_dict()/named_parameters() are unchanged), one for gradie
 into it directly by the split-K GEMM, the rest is copied in by post-accumulate-grad hooks), two for the moments, and a
 bf16 shadow that the update kernel refreshes in the same pass -- the forward GEMMs read the shadow, so no per-parameter
 cast kernels remain.  Parameters that never receive a gradient stay outside (torch.optim skips them as well).
+
+torch.optim.AdamW semantics kept exactly: a parameter whose .grad is None at step() is not touched (no weight decay, no
+moment decay, its own step count does not advance -- FlatAdamW.step updates only the flat ranges that received a
+gradient); clipping / skipping follow native_scaler.py:20-40 but stay on the device (mmae_adamw_control).  One
+restriction, enforced loudly: ONE backward per zero_grad() -- weight gradients that producers write straight into the flat
+buffer are assigned, not accumulated (the reference never accumulates either: pretrain_mmae.py:510-513).
 """
 import ctypes
 from typing import Dict, Iterable, List, Optional, Tuple
@@ -41,6 +47,9 @@ class FlatAdamW:
         self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
         self._ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self._norm = torch.empty(1, dtype=torch.float32, device=dev)
+        self._ctl = torch.zeros(4, dtype=torch.float32, device=dev)     # mmae_adamw_control: multiplier, skip, #skipped, norm
+        self._pstep: Dict[int, int] = {id(p): 0 for p in self.params}    # per-parameter step counts, as torch keeps them
+        self._in_place = set()             # ids of weights whose gradient a producer wrote in place since zero_grad()
         with torch.no_grad():
             for p in self.params:
                 o = self.offsets[id(p)]
@@ -85,11 +94,14 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none: bool = True):
         self._pending.clear()
+        self._in_place.clear()
         for p in self.params:
             p.grad = None
         self.grads.zero_()
 
     def grad_norm(self) -> torch.Tensor:
+        """L2 norm over the flat gradient buffer (a parameter without a gradient contributes its zero-filled range, like
+        get_grad_norm_ skipping it, native_scaler.py:49-62).  Device scalar, no host sync."""
         self.flush()
         call("mmae_grad_norm", self.n, ptr(self.grads), ptr(self._ws), ptr(self._norm), stream())
         return self._norm[0]
@@ -138,24 +150,96 @@ class FlatAdamW:
         call("mmae_transpose_bf16_batched", ptr(self.shadow), ptr(self.shadow_t), ptr(self._tr_tiles),
              self._tr_tiles.shape[0], stream())
 
-    def step(self, grad_scale: float = 1.0):
+    def _update_ranges(self):
+        """[(flat offset, length, step count)] of the runs of parameters that hold a gradient (torch.optim.AdamW skips
+        `p.grad is None`), each parameter's own step count advanced; one run covering everything in the usual case."""
+        runs, cur = [], None
+        for p in self.params:
+            if p.grad is None:
+                cur = None
+                continue
+            st = self._pstep[id(p)] = self._pstep[id(p)] + 1
+            o = self.offsets[id(p)]
+            end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if cur is not None and cur[2] == st and cur[0] + cur[1] == o:
+                cur[1] = end - cur[0]
+            else:
+                cur = [o, end - o, st]
+                runs.append(cur)
+        return runs
+
+    def step(self, grad_scale: float = 1.0, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None,
+             check_finite: bool = False):
+        """AdamW update of every parameter that received a gradient since zero_grad().
+        clip_grad: global-norm clipping (torch.nn.utils.clip_grad_norm_); skip_grad: no update when the norm reaches it
+        (native_scaler.py:27-32); check_finite: no update when the norm is inf / NaN (what torch's GradScaler does for the
+        reference).  All three are decided on the device from mmae_grad_norm's result -- no host synchronisation; see
+        last_step_skipped() / last_grad_norm() to read the outcome."""
         g = self.param_groups[0]
         self.flush()
         self.steps += 1
-        call("mmae_adamw_step", self.n, ptr(self.master), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             ptr(self.shadow), float(g["lr"]) * float(g.get("lr_scale", 1.0)), self.betas[0], self.betas[1], self.eps,
-             float(g["weight_decay"]), self.steps, float(grad_scale), stream())
+        ctl = clip_grad is not None or skip_grad is not None or check_finite
+        if ctl:
+            call("mmae_grad_norm", self.n, ptr(self.grads), ptr(self._ws), ptr(self._norm), stream())
+            call("mmae_adamw_control", ptr(self._norm), float(clip_grad or 0.0), float(skip_grad or 0.0), float(grad_scale),
+                 ptr(self._ctl), stream())
+        lr = float(g["lr"]) * float(g.get("lr_scale", 1.0))
+        for o, n, st in self._update_ranges():
+            sl = slice(o, o + n)
+            if ctl:
+                call("mmae_adamw_step_ctl", n, ptr(self.master[sl]), ptr(self.grads[sl]), ptr(self.exp_avg[sl]),
+                     ptr(self.exp_avg_sq[sl]), ptr(self.shadow[sl]), lr, self.betas[0], self.betas[1], self.eps,
+                     float(g["weight_decay"]), st, ptr(self._ctl), stream())
+            else:
+                call("mmae_adamw_step", n, ptr(self.master[sl]), ptr(self.grads[sl]), ptr(self.exp_avg[sl]),
+                     ptr(self.exp_avg_sq[sl]), ptr(self.shadow[sl]), lr, self.betas[0], self.betas[1], self.eps,
+                     float(g["weight_decay"]), st, float(grad_scale), stream())
+        if ctl:
+            absent = [p for p in self.params if p.grad is None]
+            if absent and self.last_step_skipped():
+                # the kernels bias-correct with (host count - skipped steps so far); a parameter that sat this skipped step
+                # out must not lose a step for it.  Host sync, only when the set of used parameters varies (downstream).
+                for p in absent:
+                    self._pstep[id(p)] += 1
         self._refresh_transposed()
+
+    def last_step_skipped(self) -> bool:
+        """Host sync: did the device-side control skip the most recent controlled step()?"""
+        return bool(self._ctl[1].item() != 0.0)
+
+    def last_grad_norm(self) -> torch.Tensor:
+        """Device scalar: the unscaled norm the most recent controlled step() saw (native_scaler's return value)."""
+        return self._ctl[3]
+
+    def skipped_steps(self) -> int:
+        """Host sync: number of controlled steps skipped so far (they do not count towards the bias correction)."""
+        return int(self._ctl[2].item())
+
+    def param_step(self, p) -> int:
+        """torch.optim.AdamW's state[p]['step'] for this parameter (host sync through skipped_steps())."""
+        return max(0, self._pstep[id(p)] - self.skipped_steps())
 
     # -- checkpoint shell (moments per parameter name are produced by the caller from these flat views) ---------------
     def state_dict(self):
-        return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+        sk = self.skipped_steps()
+        return {"steps": self.steps - sk, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_steps": [max(0, self._pstep[id(p)] - sk) for p in self.params],
                 "lr": self.param_groups[0]["lr"], "weight_decay": self.param_groups[0]["weight_decay"]}
 
     def load_state_dict(self, sd):
         self.steps = int(sd["steps"])
+        ps = sd.get("param_steps") or [self.steps] * len(self.params)
+        self._pstep = {id(p): int(st) for p, st in zip(self.params, ps)}
+        self._ctl.zero_()
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.refresh_shadow()
+
+    def set_param_steps(self, steps: Dict[int, int]):
+        """{id(parameter): step count}: restores torch-layout optimizer state (checkpoint.load_optimizer_state_dict)."""
+        for p in self.params:
+            self._pstep[id(p)] = int(steps.get(id(p), 0))
+        self.steps = max(self._pstep.values()) if self._pstep else 0
+        self._ctl.zero_()
 
 
 def shadow_of(ws, dtype) -> Optional[torch.Tensor]:
@@ -192,6 +276,10 @@ def grads_written_in_place(ws) -> None:
     (the DP reducer's bucket accounting) that post-accumulate hooks would have run."""
     for w in ws:
         eng = w._mmae_flat[0]
+        if id(w) in eng._in_place:
+            raise RuntimeError("a second backward() wrote the in-place weight gradient of a parameter before zero_grad(): "
+                               "gradient accumulation is not supported by the flat engine (one backward per zero_grad)")
+        eng._in_place.add(id(w))
         eng._pending.pop(id(w), None)
         w.grad = w._mmae_grad
         for cb in eng.ready_callbacks:

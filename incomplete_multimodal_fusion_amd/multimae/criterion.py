@@ -49,6 +49,20 @@ class MaskedL1Loss(_MaskedPixelLoss):      # criterion.py:118-172
     kind = 1
 
 
+class MaskedCrossEntropyLoss(nn.Module):   # criterion.py:24-58 (the `dnw` modality of pretrain_mmae_my.py:67-74)
+    def __init__(self, patch_size: int = 16, stride: int = 1, label_smoothing: float = 0.0):
+        super().__init__()
+        self.patch_size, self.stride, self.label_smoothing = patch_size, stride, label_smoothing
+        self.scale_factor = patch_size // stride
+
+    def forward(self, input, target, mask=None):
+        return ops.masked_ce_image(input, target, mask, self.scale_factor, self.label_smoothing)
+
+    def forward_tokens(self, tokens, target, mask=None):
+        C = tokens.shape[1] // (self.scale_factor * self.scale_factor)
+        return ops.masked_ce_tokens(tokens, target, mask, C, self.scale_factor, self.label_smoothing)
+
+
 def dino_loss_func(student_output, teacher_output, teacher_temp=0.04, student_temp=0.1):   # criterion.py:328-335
     return ops.dino_loss(student_output, teacher_output, teacher_temp, student_temp)
 
@@ -82,7 +96,29 @@ def vicreg(repr_a, repr_b, l=25, mu=25, nu=1):
 
 
 class DINOLoss(nn.Module):
+    """criterion.py:270-317 -- constructed only in a commented-out line of the reference driver (pretrain_mmae.py:273);
+    restated for API completeness in plain torch ((B, out_dim) tensors, not on the hot path).  The reference loops over the
+    ROWS of the two (B, D) inputs as if they were views: loss = mean over ordered pairs t != s of
+    sum_d -softmax((teacher_t - center) / Tt)_d * log_softmax(student_s / Ts)_d  (:281-299, vectorised here); the centre is
+    an EMA of the mean over ALL elements of the normalised teacher batch (`torch.cat(rows).mean(dim=0)`, :309-314)."""
+
     def __init__(self, out_dim, teacher_temp=0.04, student_temp=0.1, center_momentum=0.9):
         super().__init__()
-        raise NotImplementedError("DINOLoss (criterion.py:270-317) is commented out in the reference driver "
-                                  "(pretrain_mmae.py:273) and is not part of the built path")
+        self.student_temp, self.teacher_temp, self.center_momentum = student_temp, teacher_temp, center_momentum
+        self.register_buffer("center", torch.zeros(1, out_dim))
+
+    def forward(self, student_output, teacher_output):
+        student_output = F.normalize(student_output.float(), dim=1)
+        teacher_output = F.normalize(teacher_output.float(), dim=1)
+        s = F.log_softmax(student_output / self.student_temp, dim=-1)                             # (B, D)
+        t = F.softmax((teacher_output - self.center) / self.teacher_temp, dim=-1).detach()        # (B, D)
+        pair = -(t @ s.t())                                                                       # [t_idx, s_idx]
+        B = pair.shape[0]
+        total = (pair.sum() - torch.diagonal(pair).sum()) / (B * (B - 1))
+        self.update_center(teacher_output)
+        return total
+
+    @torch.no_grad()
+    def update_center(self, teacher_output):
+        batch_center = teacher_output.mean().reshape(1)
+        self.center = self.center * self.center_momentum + (1 - self.center_momentum) * batch_center

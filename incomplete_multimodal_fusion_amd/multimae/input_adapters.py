@@ -73,6 +73,19 @@ class _GridAdapter(nn.Module):
 class PatchedInputAdapter(_GridAdapter):
     has_projection = True
 
+    # -- what MultiMAE's packed patch embedding needs from a modality adapter ----------------------------------------------
+    @property
+    def packed_channels(self) -> int:
+        return self.num_channels
+
+    def packed_image(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, C, H, W) fp32 image whose kept patches are gathered into the shared embedding GEMM."""
+        return x
+
+    def packed_weight(self) -> torch.Tensor:
+        """(D, C*ph*pw) conv weight in (c ph pw) column order."""
+        return self.proj.weight.reshape(self.dim_tokens, -1)
+
     def forward(self, x):
         B, C, H, W = x.shape
         nh, nw = self._grid(H, W)
@@ -93,3 +106,62 @@ class FusionInputAdapter(_GridAdapter):
     def forward(self, x):
         assert x.shape[1] == self.num_patches
         return x + self.posemb_rows()[None]
+
+
+class SemSegInputAdapter(_GridAdapter):
+    """Class-map modality (reference: input_adapters.py:209-328; the `dnw` land-cover input of the 4-modality driver,
+    pretrain_mmae_my.py:67-74): x (B, H, W) int64 -> class_emb lookup (num_classes, dim_class_emb) -> Conv2d(k = s = patch).
+    State-dict keys kept: pos_emb, class_emb.weight, proj.{weight,bias}.
+
+    Computed here as ONE GEMM over the one-hot class image: proj(class_emb[x]) = W_c @ onehot(x) with the composed weight
+    W_c[d, (k, i, j)] = sum_c proj.weight[d, c, i, j] * class_emb[k, c] -- exact algebra (each pixel selects one embedding
+    row), and it lets the modality share MultiMAE's single kept-patch embedding GEMM.  Gradients reach class_emb and proj
+    through the composition (autograd on the small einsum)."""
+    has_projection = False
+
+    def __init__(self, num_classes: int, stride_level: int, patch_size_full: Union[int, Tuple[int, int]],
+                 dim_tokens: Optional[int] = None, sincos_pos_emb: bool = True, learnable_pos_emb: bool = False,
+                 image_size: Union[int, Tuple[int]] = 224, dim_class_emb: int = 64, interpolate_class_emb: bool = False,
+                 emb_padding_idx: int = None):
+        if interpolate_class_emb:
+            raise NotImplementedError("interpolate_class_emb=True (bilinear pooling of class embeddings) is not built; the "
+                                      "reference driver passes False (pretrain_mmae_my.py:70-71)")
+        self.num_classes = num_classes + (1 if emb_padding_idx is not None else 0)
+        self.dim_class_emb, self.interpolate_class_emb, self.emb_padding_idx = dim_class_emb, False, emb_padding_idx
+        super().__init__(self.num_classes, stride_level, patch_size_full, dim_tokens, sincos_pos_emb, learnable_pos_emb,
+                         image_size)
+
+    def init(self, dim_tokens: int = 768):
+        super().init(dim_tokens)
+        self.class_emb = nn.Embedding(self.num_classes, self.dim_class_emb, padding_idx=self.emb_padding_idx)
+        trunc_normal_(self.class_emb.weight, std=0.02)
+        self.proj = nn.Conv2d(self.dim_class_emb, dim_tokens, kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_emb', 'class_emb'}
+
+    @property
+    def packed_channels(self) -> int:
+        return self.num_classes
+
+    def packed_image(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 3 and not x.dtype.is_floating_point, "class map must be (B, H, W) integer"
+        return F.one_hot(x.long(), self.num_classes).permute(0, 3, 1, 2).to(torch.float32).contiguous()
+
+    def packed_weight(self) -> torch.Tensor:
+        w = torch.einsum('dcij,kc->dkij', self.proj.weight.float(), self.class_emb.weight.float())
+        return w.reshape(self.dim_tokens, -1)
+
+    def forward(self, x):
+        B, H, W = x.shape
+        nh, nw = self._grid(H, W)
+        assert self.P_H == self.P_W
+        T = compute_dtype(self.proj.weight)
+        K = self.num_classes * self.P_H * self.P_W
+        patches = ops.patchify_gather([self.packed_image(x)], [0], -1, K, self.P_H, None, None, nh * nw, T)
+        tok = linear(patches, self.packed_weight(), self.proj.bias)
+        pe = self.pos_emb
+        if pe.shape[-2:] != (nh, nw):
+            pe = F.interpolate(pe, size=(nh, nw), mode='bilinear')                 # reference :322 (bilinear here)
+        return tok.reshape(B, nh * nw, self.dim_tokens).float() + pe.flatten(2).transpose(1, 2)

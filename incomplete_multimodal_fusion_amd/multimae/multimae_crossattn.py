@@ -77,7 +77,14 @@ class MultiMAE(nn.Module):
             self.output_adapters = None
         self.domains = [d for d in input_adapters if d != 'fusion']
         assert num_fusion_tokens == input_adapters['s1'].num_patches          # reference :87
-        assert len(return_token_types) == len(self.domains) + 1, "one return token per modality plus fusion"
+        # Any number M <= 7 of modalities (the reference hard-codes s1/s2/dem, :402-407; its 4-modality sibling
+        # multimae_quadruplet.py adds dnw): one return token per modality in adapter order, then the fusion type last --
+        # the pool / Zorro rules are built from that order on the device (csrc/masks.hip).
+        M = len(self.domains)
+        assert 1 <= M <= 7, "1..7 modalities"
+        assert len(return_token_types) == M + 1, "one return token per modality plus fusion"
+        assert [t.value for t in return_token_types] == list(range(M + 1)), \
+            "return_token_types must be (modality 0, ..., modality M-1, FUSION) with values 0..M"
 
         self.dim_tokens, self.depth, self.heads, self.dim_head = dim_tokens, depth, heads, dim_head
         self.max_return_tokens = len(return_token_types)
@@ -207,7 +214,7 @@ class MultiMAE(nn.Module):
         packed row space.  Returns (descriptors, xm, xf, pending residual deltas, tap list): the residual stream is
         (xm, xf) PLUS the pending deltas, which the caller's next add+LayerNorm pass folds in.  `taps`: layer indices
         after which the fusion tokens (B, P, D) are materialised (downstream feature taps)."""
-        B, _, H, W = x[doms[0]].shape
+        B, H, W = x[doms[0]].shape[0], x[doms[0]].shape[-2], x[doms[0]].shape[-1]
         device = x[doms[0]].device
         M, D, Hh, dh = len(doms), self.dim_tokens, self.heads, self.dim_head
         ps = self.input_adapters[doms[0]].P_H
@@ -220,12 +227,13 @@ class MultiMAE(nn.Module):
         BN, BP = B * N, B * P
 
         # -- patch embedding of the kept patches: one gather kernel + one GEMM for all modalities --------------------------
-        Ks = [self.input_adapters[d].num_channels * ps * ps for d in doms]
+        Ks = [self.input_adapters[d].packed_channels * ps * ps for d in doms]
         koff = [sum(Ks[:i]) for i in range(M)]
         onehot = sum(Ks)
         Kcat = onehot + ((M + 7) // 8) * 8
-        pcat = ops.patchify_gather([x[d] for d in doms], koff, onehot, Kcat, ps, desc.tok_mod, desc.tok_patch, N, T)
-        wcat = torch.cat([self.input_adapters[d].proj.weight.reshape(D, -1) for d in doms] +
+        pcat = ops.patchify_gather([self.input_adapters[d].packed_image(x[d]) for d in doms], koff, onehot, Kcat, ps,
+                                   desc.tok_mod, desc.tok_patch, N, T)
+        wcat = torch.cat([self.input_adapters[d].packed_weight() for d in doms] +
                          [torch.stack([self.input_adapters[d].proj.bias for d in doms], dim=1),
                           pcat.new_zeros(D, Kcat - onehot - M, dtype=torch.float32)], dim=1)
         tok = linear(pcat, wcat, once=True)                                                   # (B*N, D), bias included
@@ -294,8 +302,10 @@ class MultiMAE(nn.Module):
         doms = self.domains
         for d in doms:
             _ = x[d]                                    # every configured modality must be present (:402-407)
-        if exists(return_token_indices):
-            raise NotImplementedError("return_token_indices is not used by any reference driver and is not built")
+        if exists(return_token_indices):                # reference :478-484
+            assert len(set(return_token_indices)) == len(return_token_indices), 'all indices must be unique'
+            assert all(i < self.max_return_tokens for i in return_token_indices), \
+                'indices must range from 0 to max_num_return_tokens - 1'
         M, D, Hh, dh = len(doms), self.dim_tokens, self.heads, self.dim_head
         I = Hh * dh
         ad0 = self.input_adapters[doms[0]]
@@ -348,6 +358,8 @@ class MultiMAE(nn.Module):
         pooled = linear(a, ap.to_out.weight).float()                                        # (B*R, D)
         pooled = pooled + self.mlp(ops.layernorm(pooled, self.norm.gamma, out_dtype=T)).float()
         return_tokens = pooled.reshape(B, R, D)
+        if exists(return_token_indices):                # a row subset of the pooled queries (each query row is independent)
+            return_tokens = return_tokens[:, torch.tensor(list(return_token_indices), dtype=torch.long, device=device)]
 
         if self.output_adapters is None:
             full = torch.cat([ori_tokens, enc_fus], dim=1)

@@ -27,6 +27,14 @@ class TokenTypes(Enum):          # zorro_utils.py:14-18
     FUSION = 3
 
 
+class TokenTypesQuad(Enum):      # pretraining/multimae/zorro_utils_quadruplet.py:17-22 (4-modality driver)
+    S1 = 0
+    S2 = 1
+    DEM = 2
+    DNW = 3
+    FUSION = 4
+
+
 def exists(val):
     return val is not None
 

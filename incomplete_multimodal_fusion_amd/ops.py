@@ -111,7 +111,7 @@ def _split_k(rows: int, n_out: int, n_in: int) -> int:
 _SPLITK_CAP = int(os.environ.get("MMAE_SPLITK_CAP", "256"))     # workgroups the split aims at (256 CUs)
 _SPLITK_MAX = int(os.environ.get("MMAE_SPLITK_MAX", "32"))
 _WGRAD_STREAMS = {}
-WGRAD_STREAM_PRIORITY = int(__import__('os').environ.get('MMAE_WGRAD_PRIO', '-1'))   # high priority: own HW queue
+WGRAD_STREAM_PRIORITY = int(os.environ.get('MMAE_WGRAD_PRIO', '-1'))   # high priority: own HW queue
 WGRAD_SIDE_STREAM = True     # weight-gradient GEMMs of single-use weights run on a side HIP stream (see _Linear.backward)
 
 
@@ -743,6 +743,48 @@ def masked_loss_image(pred, target, mask, kind: int, patch: int):
 def masked_loss_tokens(tok, target, mask, kind: int, patch: int):
     """Fused unpatchify+loss: tok (B*P, C*patch^2) decoder output in (c ph pw) order, target image (B,C,H,W)."""
     return _MaskedLoss.apply(tok, target, mask, kind, patch, True, tuple(target.shape))
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, smooth, patch, is_tokens, shape):
+        B, C, H, W = shape
+        pred = _c(pred)
+        target = _c(target.to(torch.int64))
+        assert target.shape == (B, H, W), "class-map target must be (B, H, W)"
+        P = (H // patch) * (W // patch)
+        dev = pred.device
+        if mask is not None:
+            mask = _c(mask.to(torch.int64))
+        partial = torch.empty(B * P, dtype=torch.float32, device=dev)
+        den = torch.empty(B, dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        call("mmae_masked_ce_loss_fwd", dt(pred), int(is_tokens), B, C, H, W, patch, ptr(pred), ptr(target), ptr(mask),
+             float(smooth), ptr(partial), ptr(den), ptr(stats), stream())
+        ctx.save_for_backward(pred, target, mask, den, stats)
+        ctx.cfg = (smooth, patch, is_tokens, shape)
+        return stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, mask, den, stats = ctx.saved_tensors
+        smooth, patch, is_tokens, (B, C, H, W) = ctx.cfg
+        g = _c(g.float()).reshape(1)
+        gp = torch.empty_like(pred)
+        call("mmae_masked_ce_loss_bwd", dt(pred), int(is_tokens), B, C, H, W, patch, ptr(pred), ptr(target), ptr(mask),
+             float(smooth), ptr(den), ptr(stats), ptr(g), ptr(gp), stream())
+        return gp, None, None, None, None, None, None
+
+
+def masked_ce_image(pred, target, mask, patch: int, label_smoothing: float = 0.0):
+    """pred (B,C,H,W) logits, target (B,H,W) int64 class ids, mask (B,P) {0,1} or None."""
+    return _MaskedCE.apply(pred.float(), target, mask, label_smoothing, patch, False, tuple(pred.shape))
+
+
+def masked_ce_tokens(tok, target, mask, C: int, patch: int, label_smoothing: float = 0.0):
+    """Fused unpatchify + cross-entropy: tok (B*P, C*patch^2) decoder logits in (c ph pw) order, target (B,H,W)."""
+    B, H, W = target.shape
+    return _MaskedCE.apply(tok, target, mask, label_smoothing, patch, True, (B, C, H, W))
 
 
 # ------------------------------------------------------------------------------------------------ contrastive heads

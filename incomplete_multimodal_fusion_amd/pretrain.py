@@ -2,18 +2,26 @@
 
 Reference: pretraining/pretrain_mmae.py -- DOMAIN_CONF :45-72, get_model :188-248, and the step of train_one_epoch
 :447-517 (H2D of the tile stack, autocast forward, per-task masked losses :479-486, 3x DINO-style contrastive loss
-:489-493, weighted sum :499-500, backward, optimizer step).  Logging / checkpointing / dataset code is out of scope
-(SURVEY.md section 2).  Device tensors only.
+:489-493, weighted sum :499-500, backward, optimizer step through NativeScaler with clip_grad / skip_grad,
+utils/native_scaler.py:20-40, step-level cosine schedule :65-82); the hard-negative contrastive variant of
+pretrain_mmae_s2dsm.py:482-492; the 4-modality domain table of pretrain_mmae_my.py:46-81.  Logging / dataset code is out
+of scope.  Device tensors only.
 """
+import math
 from functools import partial
 from typing import Dict, Iterable, Optional
 
+import numpy as np
 import torch
+from torch import nn
 
 from . import ops
-from .multimae import (FusionInputAdapter, MaskedL1Loss, MaskedMSELoss, PatchedInputAdapter, SpatialOutputAdapter,
-                       TokenTypes, dino_loss_func)
+from .multimae import (FusionInputAdapter, HardNegtive_loss, MaskedL1Loss, MaskedMSELoss, PatchedInputAdapter,
+                       SpatialOutputAdapter, TokenTypes, dino_loss_func)
 from .multimae import multimae_crossattn as mc
+from .multimae.criterion import MaskedCrossEntropyLoss
+from .multimae.input_adapters import SemSegInputAdapter
+from .multimae.zorro_utils import TokenTypesQuad
 
 DOMAIN_CONF = {                                   # pretrain_mmae.py:45-72
     's1': {'channels': 1, 'stride_level': 1, 'loss': MaskedMSELoss},
@@ -22,19 +30,40 @@ DOMAIN_CONF = {                                   # pretrain_mmae.py:45-72
     'fusion': {'channels': 1, 'stride_level': 1},
 }
 
+DOMAIN_CONF_QUAD = {                              # pretrain_mmae_my.py:46-81 (s1-s2-dem-dnw)
+    's1': {'channels': 2, 'stride_level': 1, 'loss': MaskedMSELoss},
+    's2': {'channels': 4, 'stride_level': 1, 'loss': MaskedMSELoss},
+    'dem': {'channels': 1, 'stride_level': 1, 'loss': MaskedL1Loss},
+    'dnw': {'num_classes': 9, 'channels': 9, 'stride_level': 1, 'dim_class_emb': 64,
+            'loss': partial(MaskedCrossEntropyLoss, label_smoothing=0.0)},
+    'fusion': {'channels': 1, 'stride_level': 1},
+}
+
 PRESETS = {'tiny': (192, 12, 3), 'small': (384, 12, 8), 'base': (768, 12, 8), 'large': (1024, 24, 8)}
 
 
-def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=('s1', 's2', 'dem'), patch_size: int = 16,
+def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=None, patch_size: int = 16,
               input_size: int = 256, decoder_dim: int = 256, decoder_depth: int = 2, decoder_num_heads: int = 8,
-              dim_head: int = 64):
+              dim_head: int = 64, domain_conf: Optional[dict] = None):
     """Adapters + model as get_model builds them (pretrain_mmae.py:193-246); `model` picks the size preset (the
-    reference ignores --model and always builds the tiny factory, :239 -- SURVEY.md 0.5)."""
-    input_adapters = {
-        d: PatchedInputAdapter(num_channels=DOMAIN_CONF[d]['channels'], stride_level=DOMAIN_CONF[d]['stride_level'],
-                               patch_size_full=patch_size, image_size=input_size) for d in in_domains}
+    reference ignores --model and always builds the tiny factory, :239 -- SURVEY.md 0.5).  `domain_conf` defaults to the
+    3-modality table, or to the 4-modality one when 'dnw' is among the domains.  NOTE: the reference has no M = 4 model
+    WITH fusion blocks (multimae_quadruplet.py has none); that configuration is this package's extension of the
+    3-modality algorithm to M modalities and has no reference-generated fixture."""
+    out_domains = tuple(in_domains) if out_domains is None else tuple(out_domains)
+    conf = domain_conf or (DOMAIN_CONF_QUAD if 'dnw' in in_domains else DOMAIN_CONF)
+
+    def in_adapter(d):
+        c = conf[d]
+        if 'num_classes' in c:
+            return SemSegInputAdapter(num_classes=c['num_classes'], stride_level=c['stride_level'],
+                                      patch_size_full=patch_size, image_size=input_size,
+                                      dim_class_emb=c.get('dim_class_emb', 64), interpolate_class_emb=False)
+        return PatchedInputAdapter(num_channels=c['channels'], stride_level=c['stride_level'], patch_size_full=patch_size,
+                                   image_size=input_size)
+    input_adapters = {d: in_adapter(d) for d in in_domains}
     output_adapters = {
-        d: SpatialOutputAdapter(num_channels=DOMAIN_CONF[d]['channels'], stride_level=DOMAIN_CONF[d]['stride_level'],
+        d: SpatialOutputAdapter(num_channels=conf[d]['channels'], stride_level=conf[d]['stride_level'],
                                 patch_size_full=patch_size, dim_tokens=decoder_dim, depth=decoder_depth,
                                 num_heads=decoder_num_heads, use_task_queries=True, task=d,
                                 context_tasks=list(in_domains), use_xattn=True) for d in out_domains}
@@ -42,19 +71,79 @@ def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=(
                                                   image_size=input_size)
     D, depth, heads = PRESETS[model]
     P = (input_size // patch_size) ** 2
+    M = len(in_domains)
+    if tuple(in_domains) == ('s1', 's2', 'dem'):
+        rtt = (TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION)
+    elif tuple(in_domains) == ('s1', 's2', 'dem', 'dnw'):
+        rtt = tuple(TokenTypesQuad)
+    else:
+        from enum import Enum
+        rtt = tuple(Enum('TokenTypesM', [(d.upper(), i) for i, d in enumerate(in_domains)] + [('FUSION', M)]))
     return mc.MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters, num_global_tokens=1,
                        dim_tokens=D, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4, num_fusion_tokens=P,
-                       return_token_types=(TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION),
-                       drop_path_rate=0.0)
+                       return_token_types=rtt, drop_path_rate=0.0)
 
 
-def make_loss_fns(out_domains=('s1', 's2', 'dem'), patch_size: int = 16):
-    return {d: DOMAIN_CONF[d]['loss'](patch_size=patch_size, stride=DOMAIN_CONF[d]['stride_level']) for d in out_domains}
+def make_loss_fns(out_domains=('s1', 's2', 'dem'), patch_size: int = 16, domain_conf: Optional[dict] = None):
+    conf = domain_conf or (DOMAIN_CONF_QUAD if 'dnw' in out_domains else DOMAIN_CONF)
+    return {d: conf[d]['loss'](patch_size=patch_size, stride=conf[d]['stride_level']) for d in out_domains}
+
+
+class NoWeightingStrategy(nn.Module):             # utils/task_balancing.py:11-19
+    def __init__(self, **kwargs):
+        super().__init__()
+
+    def forward(self, task_losses):
+        return task_losses
+
+
+class UncertaintyWeightingStrategy(nn.Module):    # utils/task_balancing.py:21-44
+    def __init__(self, tasks):
+        super().__init__()
+        self.tasks = tasks
+        self.log_vars = nn.Parameter(torch.zeros(len(tasks)))
+
+    def forward(self, task_losses):
+        losses = torch.stack([l.float() for l in task_losses.values()])
+        nonzero = (losses != 0.0)
+        losses = (torch.exp(-self.log_vars) * losses + self.log_vars) * nonzero     # a dropped task (loss 0) stays 0
+        out = task_losses.copy()
+        out.update(zip(out, losses))
+        return out
+
+
+def create_optimizer(model, balancer=None, lr: float = 1e-4, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8,
+                     balancer_lr_scale: float = 1.0, fused: bool = False):
+    """The reference trainer's optimizer (utils/optim_factory.py:136-179, dict path; call site pretrain_mmae.py:351-352):
+    torch AdamW over two groups -- the model's trainable parameters (lr_scale 1) and the loss balancer's
+    (lr_scale balancer_lr_scale) -- with weight decay on EVERY parameter (the dict path skips the no-decay filter)."""
+    groups = [{"params": [p for _, p in model.named_parameters() if p.requires_grad], "lr_scale": 1.0},
+              {"params": [p for _, p in (balancer.named_parameters() if balancer is not None else []) if p.requires_grad],
+               "lr_scale": balancer_lr_scale}]
+    kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+    if fused:
+        kw["fused"] = True
+    return torch.optim.AdamW(groups, **kw)
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
+    """Per-iteration schedule: linear warm-up then half-cosine (utils/native_scaler.py:65-82, same signature / result)."""
+    warmup_iters = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    sched = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / len(iters))) for i in iters])
+    sched = np.concatenate((warm, sched))
+    assert len(sched) == epochs * niter_per_ep
+    return sched
 
 
 def step_losses(out, tasks_dict: Dict[str, torch.Tensor], masks: Dict[str, torch.Tensor], patch_size: int = 16,
-                loss_fns=None, contra_weight: float = 0.3):
-    """pretrain_mmae.py:479-500 with NoWeightingStrategy (utils/task_balancing.py:11-19)."""
+                loss_fns=None, contra_weight: Optional[float] = None, contra: str = 'dino', loss_balancer=None,
+                contra_loss=None):
+    """pretrain_mmae.py:479-500 with NoWeightingStrategy (utils/task_balancing.py:11-19) by default.
+    contra='dino': sum_m dino_loss_func(return_token_m, pooled_m), weight 0.3 (pretrain_mmae.py:493,:500);
+    contra='hardneg': HardNegtive_loss over every pair of the pooled return tokens (modalities + fusion), weight 1
+    (pretrain_mmae_s2dsm.py:482-492 written for M modalities)."""
     preds, _, pooled, _, _, *rets = out
     loss_fns = loss_fns or make_loss_fns(tuple(preds.keys()), patch_size)
     task_losses = {}
@@ -65,32 +154,67 @@ def step_losses(out, tasks_dict: Dict[str, torch.Tensor], masks: Dict[str, torch
             task_losses[task] = fn.forward_tokens(pred.tokens, tasks_dict[task], mask=masks.get(task, None))
         else:
             task_losses[task] = fn(pred, tasks_dict[task], mask=masks.get(task, None))
-    feats = torch.chunk(pooled, pooled.shape[1], dim=1)                        # :489-490 (squeeze the token axis)
-    loss_contra = sum(dino_loss_func(r.squeeze(1), f.squeeze(1)) for r, f in zip(rets, feats))   # :493
-    loss = sum(task_losses.values()) + contra_weight * loss_contra             # :499-500
+    feats = [f.squeeze(1) for f in torch.chunk(pooled, pooled.shape[1], dim=1)]   # :489-490 (squeeze the token axis)
+    if contra == 'dino':
+        loss_contra = sum(dino_loss_func(r.squeeze(1), f) for r, f in zip(rets, feats))          # :493
+        w = 0.3 if contra_weight is None else contra_weight
+    elif contra == 'hardneg':
+        fn = contra_loss or HardNegtive_loss()
+        loss_contra = sum(fn(feats[i], feats[j]) for i in range(len(feats)) for j in range(i + 1, len(feats)))
+        w = 1.0 if contra_weight is None else contra_weight
+    else:
+        raise ValueError("contra must be 'dino' or 'hardneg'")
+    weighted = loss_balancer(task_losses) if loss_balancer is not None else task_losses
+    loss = sum(weighted.values()) + w * loss_contra                                # :499-500
     return task_losses, loss_contra, loss
 
 
 class PretrainStep:
-    """One optimizer step on a batch of tiles already resident on the device.  No host synchronisation."""
+    """One optimizer step on a batch of tiles already resident on the device.  No host synchronisation.
 
-    def __init__(self, model, optimizer, num_encoded_tokens: int, in_domains=('s1', 's2', 'dem'), alphas: float = 1.0,
+    clip_grad / skip_grad: NativeScaler's options (utils/native_scaler.py:20-40; the driver passes max_norm /
+    max_skip_norm, pretrain_mmae.py:510-513).  With the flat engine they -- and the non-finite-gradient guard torch's
+    GradScaler provides for the reference -- are evaluated on the device (engine.FlatAdamW.step); with a torch optimizer
+    clip_grad uses torch.nn.utils.clip_grad_norm_ and skip_grad costs one host sync."""
+
+    def __init__(self, model, optimizer, num_encoded_tokens: int, in_domains=None, alphas: float = 1.0,
                  sample_tasks_uniformly: bool = False, autocast: bool = True, patch_size: int = 16,
-                 grad_reducer=None, side_stream_wgrad: bool = False):
+                 grad_reducer=None, side_stream_wgrad: bool = False, clip_grad: Optional[float] = None,
+                 skip_grad: Optional[float] = None, contra: str = 'dino', contra_weight: Optional[float] = None,
+                 loss_balancer=None, check_finite: bool = True):
         self.model, self.opt = model, optimizer
-        self.N, self.in_domains, self.alphas, self.uniform = num_encoded_tokens, tuple(in_domains), alphas, sample_tasks_uniformly
+        self.in_domains = tuple(in_domains) if in_domains is not None else tuple(model.domains)
+        self.N, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
         self.autocast, self.patch = autocast, patch_size
         self.loss_fns = make_loss_fns(tuple(model.output_adapters.keys()), patch_size)
         self.reducer = grad_reducer
+        self.clip_grad, self.skip_grad, self.check_finite = clip_grad, skip_grad, check_finite
+        self.contra, self.contra_weight, self.balancer = contra, contra_weight, loss_balancer
+        self.contra_loss = HardNegtive_loss() if contra == 'hardneg' else None
         model.fuse_unpatchify_loss = True
         model.side_stream_wgrad = side_stream_wgrad
+
+    def _optimizer_step(self):
+        from .engine import FlatAdamW
+        if isinstance(self.opt, FlatAdamW):
+            self.opt.step(clip_grad=self.clip_grad, skip_grad=self.skip_grad, check_finite=self.check_finite)
+            return
+        params = [p for g in self.opt.param_groups for p in g['params'] if p.grad is not None]
+        if self.clip_grad is not None:
+            torch.nn.utils.clip_grad_norm_(params, self.clip_grad)
+        elif self.skip_grad is not None:
+            norm = torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in params]), 2.0)
+            if float(norm) >= self.skip_grad:                                     # native_scaler.py:29-32
+                return
+        self.opt.step()
 
     def __call__(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None):
         x = {t: v for t, v in tasks_dict.items() if t in self.in_domains}
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             out = self.model(x, task_masks=task_masks, num_encoded_tokens=self.N, alphas=self.alphas,
                              sample_tasks_uniformly=self.uniform)
-            task_losses, loss_contra, loss = step_losses(out, tasks_dict, out[1], self.patch, self.loss_fns)
+            task_losses, loss_contra, loss = step_losses(out, tasks_dict, out[1], self.patch, self.loss_fns,
+                                                         self.contra_weight, self.contra, self.balancer, self.contra_loss)
         self.opt.zero_grad(set_to_none=True)               # (FlatAdamW: also clears the flat gradient buffer)
         if self.reducer is not None:
             self.reducer.prepare()
@@ -98,6 +222,6 @@ class PretrainStep:
         ops.join_wgrad_stream()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
+        self._optimizer_step()
         return {'loss': loss.detach(), 'loss_contra': loss_contra.detach(),
                 **{k + '_loss': v.detach() for k, v in task_losses.items()}}

@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("MMAE_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 
 def npy(t):
@@ -55,8 +55,19 @@ def rand_init_(mod, gen, scale=0.2):
 
 
 # ----------------------------------------------------------------------------------------------
+_SEED = [0]
+
+
+def seeded():
+    """torch.manual_seed before EVERY module construction: module initialisers draw from the global RNG, and the fixtures
+    must regenerate byte for byte (`python oracle/make_golden.py` twice -> identical .npz contents)."""
+    _SEED[0] += 1
+    torch.manual_seed(4000 + _SEED[0])
+
+
 def gen_ops(ref):
     bag = Bag()
+    _SEED[0] = 0
     gen = torch.Generator().manual_seed(1234)
     R = lambda *s: torch.randn(*s, generator=gen)
 
@@ -65,6 +76,7 @@ def gen_ops(ref):
     bag.put("sincos_2x3_16", out=ref.mu.build_2d_sincos_posemb(2, 3, 16))
 
     # a7: bias-less LayerNorm (zorro_utils.py:103-110)
+    seeded()
     ln = ref.zu.LayerNorm(32); rand_init_(ln, gen)
     x = R(3, 5, 32).requires_grad_(); g = R(3, 5, 32)
     y = ln(x)
@@ -72,6 +84,7 @@ def gen_ops(ref):
     bag.put("layernorm", x=x, gamma=ln.gamma, y=y, g=g, gx=gx, ggamma=gg)
 
     # a8: Attention, self / zorro-masked (zorro_utils.py:170-194)
+    seeded()
     attn = ref.zu.Attention(dim=32, dim_head=32, heads=2); rand_init_(attn, gen)
     types = torch.tensor([0, 0, 0, 1, 1, 2, 2, 3, 3, 3])
     zmask = (types[:, None] == types[None, :]) | (types[:, None] == 3)
@@ -106,6 +119,7 @@ def gen_ops(ref):
     bag.put("attn_cross_empty", y=y)
 
     # a9: GEGLU feed-forward (zorro_utils.py:115-128); inner = int(32*4*2/3) = 85 (odd on purpose)
+    seeded()
     ff = ref.zu.FeedForward(dim=32, mult=4); rand_init_(ff, gen)
     x = R(2, 7, 32).requires_grad_(); g = R(2, 7, 32)
     y = ff(x)
@@ -115,6 +129,7 @@ def gen_ops(ref):
             **{"gw." + n: gi for (n, _), gi in zip(ff.named_parameters(), gs[1:])})
 
     # Mlp (zorro_utils.py:131-148)
+    seeded()
     mlp = ref.zu.Mlp(in_features=32, hidden_features=128); rand_init_(mlp, gen)
     x = R(2, 4, 32).requires_grad_(); g = R(2, 4, 32)
     y = mlp(x)
@@ -124,6 +139,7 @@ def gen_ops(ref):
             **{"gw." + n: gi for (n, _), gi in zip(mlp.named_parameters(), gs[1:])})
 
     # a10: Block (zorro_utils.py:227-240)
+    seeded()
     blk = ref.zu.Block(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=ref.zu.LayerNorm); rand_init_(blk, gen)
     x = R(2, 10, 32).requires_grad_(); g = R(2, 10, 32)
     y = blk(x, zmask)
@@ -133,6 +149,7 @@ def gen_ops(ref):
             **{"gw." + n: gi for (n, _), gi in zip(blk.named_parameters(), gs[1:])})
 
     # a12: Block_Fusion, canonical downstream copy (DSI-MM/zorro_utils.py:243-258)
+    seeded()
     fus = ref.zu.Block_Fusion(dim=32, dim_head=32, heads=2, ff_mult=4, norm_layer=ref.zu.LayerNorm); rand_init_(fus, gen)
     x = R(2, 6, 4, 32).requires_grad_(); g = R(2, 6, 32)
     y = fus(x, None)
@@ -142,6 +159,7 @@ def gen_ops(ref):
             **{"gw." + n: gi for (n, _), gi in zip(fus.named_parameters(), gs[1:])})
 
     # a1: PatchedInputAdapter (input_adapters.py:97-119), C=3, patch 8, 32x32 -> 16 patches, D=32
+    seeded()
     pia = ref.ia.PatchedInputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32)
     rand_init_(pia, gen)
     x = R(2, 3, 32, 32); g = R(2, 16, 32)
@@ -150,11 +168,13 @@ def gen_ops(ref):
     bag.put("patched_input", x=x, y=y, g=g, gweight=gs[0], gbias=gs[1],
             **{"w." + k: v for k, v in pia.state_dict().items()})
     # a3: FusionInputAdapter (input_adapters.py:185-206)
+    seeded()
     fia = ref.ia.FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32)
     x = R(2, 16, 32)
     bag.put("fusion_input", x=x, y=fia(x), **{"w." + k: v for k, v in fia.state_dict().items()})
 
     # a14: SpatialOutputAdapter (output_adapters_simple.py:146-188), 2 decoder blocks @64, 2 heads (dh 32)
+    seeded()
     soa = ref.oa.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=8, dim_tokens_enc=32,
                                       dim_tokens=64, depth=2, num_heads=2, image_size=32, task="s2",
                                       context_tasks=["s1", "s2", "dem"])
@@ -195,6 +215,7 @@ def gen_ops(ref):
     bag.put("dino", student=s, teacher=t, loss=l, gstudent=gs_, gteacher=gt_)
 
     # a18: HardNegtive_loss (criterion.py:233-268); `.cuda()` at :242 made a no-op for the CPU run only
+    seeded()
     hn = ref.cr.HardNegtive_loss()
     o1 = R(4, 32).requires_grad_(); o2 = R(4, 32).requires_grad_()
     orig_cuda = torch.Tensor.cuda
@@ -307,6 +328,7 @@ def gen_masks(ref):
     replaying the same seed: Dirichlet(alphas).sample((1,)), M x rand(1,P), rand_like(mask_all)."""
     from torch.distributions.dirichlet import Dirichlet
     bag = Bag()
+    torch.manual_seed(11)
     model = ref_loader.build_reference_model(ref, channels=CHANNELS, **E2E_CFG)
     cases = []
     for seed, (P, N, B) in enumerate([(16, 24, 2), (16, 24, 2), (16, 8, 1), (16, 40, 2), (64, 96, 3),
@@ -395,14 +417,95 @@ def gen_downstream():
     np.savez_compressed(os.path.join(OUT, "downstream.npz"), **bag)
     print("downstream.npz:", len(bag), "arrays")
 
+# ----------------------------------------------------------------------------------------------
+def gen_aux():
+    """Pieces around the 3-modality hot path that rounds >= 2 build: the 4-modality driver's class-map modality
+    (SemSegInputAdapter, MaskedCrossEntropyLoss; pretrain_mmae_my.py:67-74), the step shell's schedule and balancer
+    (utils/native_scaler.py:65-82, utils/task_balancing.py:21-44), the (commented-out) DINOLoss class, and the
+    normalisation constants/functions of the input staging row f3 (utils/multimodal_dfc2023.py:18-49 -- the functions that
+    need neither rasterio nor cv2; load_* and the cv2 resize stay UNPINNED)."""
+    aux = ref_loader.load_aux()
+    bag = Bag()
+    gen = torch.Generator().manual_seed(777)
+    R = lambda *s: torch.randn(*s, generator=gen)
+
+    # SemSegInputAdapter (input_adapters.py:209-328): 5 classes, emb 8, patch 8, 32x32 -> 16 patches, D=32
+    torch.manual_seed(5001)
+    ssa = aux.ia.SemSegInputAdapter(num_classes=5, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32,
+                                    dim_class_emb=8, interpolate_class_emb=False)
+    rand_init_(ssa, gen)
+    x = torch.randint(0, 5, (2, 32, 32), generator=gen)
+    g = R(2, 16, 32)
+    y = ssa(x)
+    gs = grads_of(y, g, [ssa.class_emb.weight, ssa.proj.weight, ssa.proj.bias])
+    bag.put("semseg_input", x=x, y=y, g=g, gclass_emb=gs[0], gweight=gs[1], gbias=gs[2],
+            **{"w." + k: v for k, v in ssa.state_dict().items()})
+
+    # MaskedCrossEntropyLoss (criterion.py:24-58): mask with an empty row, no mask, zero mask, label smoothing
+    pred = R(3, 5, 32, 32).requires_grad_(); tgt = torch.randint(0, 5, (3, 32, 32), generator=gen)
+    mask = (torch.rand(3, 16, generator=gen) > 0.5).long()
+    mask[2] = 0
+    for name, ls in (("ce", 0.0), ("ce_smooth", 0.1)):
+        fn = aux.cr.MaskedCrossEntropyLoss(patch_size=8, stride=1, label_smoothing=ls)
+        l = fn(pred, tgt, mask=mask)
+        (gp,) = grads_of(l, torch.tensor(1.0), [pred])
+        bag.put("masked_" + name, pred=pred, tgt=tgt, mask=mask, loss=l, gpred=gp)
+        l = fn(pred, tgt, mask=None)
+        (gp,) = grads_of(l, torch.tensor(1.0), [pred])
+        bag.put("masked_" + name + "_nomask", loss=l, gpred=gp)
+        bag.put("masked_" + name + "_zeromask", loss=fn(pred, tgt, mask=torch.zeros(3, 16, dtype=torch.long)))
+
+    # DINOLoss class (criterion.py:270-317).  Dead code in the reference: its update_center (:309-314) raises TypeError on
+    # the (B, D) tensor its own forward hands it (`torch.cat(tensor)`), so the class cannot complete one call; only the loss
+    # expression (:281-303) is pinned here, with update_center made a no-op on this instance.
+    dl = aux.cr.DINOLoss(out_dim=32)
+    dl.update_center = lambda t: None
+    s1, t1 = R(4, 32).requires_grad_(), R(4, 32)
+    l1 = dl(s1, t1)
+    (g1,) = grads_of(l1, torch.tensor(1.0), [s1])
+    bag.put("dino_class", s1=s1, t1=t1, loss1=l1, gs1=g1)
+
+    # UncertaintyWeightingStrategy (task_balancing.py:21-44) incl. a dropped task (loss exactly 0)
+    uw = aux.tb.UncertaintyWeightingStrategy(tasks=["s1", "s2", "dem"])
+    with torch.no_grad():
+        uw.log_vars.copy_(torch.tensor([0.3, -0.2, 0.1]))
+    losses = {"s1": torch.tensor(0.7, requires_grad=True), "s2": torch.tensor(0.0, requires_grad=True),
+              "dem": torch.tensor(1.3, requires_grad=True)}
+    w = uw(losses)
+    tot = sum(w.values())
+    gl = grads_of(tot, torch.tensor(1.0), [uw.log_vars] + list(losses.values()))
+    bag.put("uncertainty", log_vars=uw.log_vars, losses=torch.stack(list(losses.values())),
+            weighted=torch.stack(list(w.values())), glog_vars=gl[0], glosses=torch.stack(gl[1:]))
+
+    # cosine_scheduler (native_scaler.py:65-82)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        bag.put("cosine", a=aux.ns.cosine_scheduler(1e-3, 1e-5, 4, 7, warmup_epochs=1),
+                b=aux.ns.cosine_scheduler(2e-4, 0.0, 3, 5, warmup_epochs=1, warmup_steps=3, start_warmup_value=1e-6),
+                c=aux.ns.cosine_scheduler(1.0, 0.1, 2, 4))
+
+    # f3 constants and the rasterio/cv2-free normalisation functions (multimodal_dfc2023.py:18-49)
+    d = aux.dfc
+    rgb = np.random.default_rng(3).uniform(0, 255, size=(3, 6, 5))
+    sar = np.random.default_rng(4).uniform(-25, 0, size=(1, 6, 5))
+    dem = np.random.default_rng(5).normal(5, 7, size=(1, 6, 5))
+    bag.put("staging", rgb_mean=d.rgb_MEAN, rgb_std=d.rgb_STD, sar_mean=d.sar_MEAN, sar_std=d.sar_STD,
+            dem_mean=d.dem_MEAN, dem_std=d.dem_STD, rgb_in=rgb, rgb_out=d.normalize_rgb(rgb.copy()),
+            sar_in=sar, sar_out=d.normalize_sar(sar.copy()), dem_in=dem, dem_out=d.normalize_dem(dem.copy()),
+            minmax_out=d.normalization(dem.copy()))
+    np.savez_compressed(os.path.join(OUT, "aux.npz"), **bag)
+    print("aux.npz:", len(bag), "arrays")
+
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(4)
+    torch.set_num_threads(1)          # single-threaded reductions: the fixtures regenerate byte for byte
     ref = ref_loader.load()
     gen_ops(ref)
     gen_e2e(ref)
     gen_masks(ref)
     gen_downstream()
+    gen_aux()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

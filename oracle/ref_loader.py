@@ -142,3 +142,48 @@ def build_downstream_backbone(ds, *, dim_tokens, depth, dim_head, heads, image_s
                               dim_tokens=dim_tokens, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4,
                               norm_layer=ds.zu.LayerNorm, in_domains=[c[0] for c in channels], frozen_stages=11,
                               pretrained="/nonexistent")
+
+
+_aux_cache = None
+
+
+def load_aux():
+    """Reference pieces outside the `multimae` package that the step shell / 4-modality driver use, loaded by file path:
+      tb  = pretraining/utils/task_balancing.py        (imports torch only)
+      ns  = pretraining/utils/native_scaler.py         (cosine_scheduler; its `from torch._six import inf` needs torch 1.x:
+            a placeholder module object named torch._six carrying `inf` is registered for the import and removed again)
+      dfc = pretraining/utils/multimodal_dfc2023.py    (normalisation constants / functions; imports rasterio and cv2 at
+            the top, both absent here: NEVER-CALLED placeholder module objects are registered for the import only, so
+            only the functions that touch neither -- normalization, normalize_rgb/sar/dem -- may be called)
+      ia  = pretraining/multimae/input_adapters.py     (SemSegInputAdapter), cr = criterion.py (MaskedCrossEntropyLoss, DINOLoss)
+    """
+    global _aux_cache
+    if _aux_cache is not None:
+        return _aux_cache
+    ref = load()
+    UT = os.path.join(REF_ROOT, "pretraining", "utils")
+
+    def by_path(name, path, placeholders=()):
+        added = []
+        for mod_name, attrs in placeholders:
+            if mod_name not in sys.modules:
+                m = types.ModuleType(mod_name)
+                for k, v in attrs.items():
+                    setattr(m, k, v)
+                sys.modules[mod_name] = m
+                added.append(mod_name)
+        try:
+            spec = importlib.util.spec_from_file_location(name, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        finally:
+            for mod_name in added:
+                del sys.modules[mod_name]
+        return mod
+    ns = types.SimpleNamespace(
+        tb=by_path("_ref_task_balancing", os.path.join(UT, "task_balancing.py")),
+        ns=by_path("_ref_native_scaler", os.path.join(UT, "native_scaler.py"), [("torch._six", {"inf": float("inf")})]),
+        dfc=by_path("_ref_multimodal_dfc2023", os.path.join(UT, "multimodal_dfc2023.py"), [("rasterio", {}), ("cv2", {})]),
+        ia=ref.ia, cr=ref.cr)
+    _aux_cache = ns
+    return ns

@@ -43,11 +43,28 @@ def test_save_and_auto_resume_layout(tmp_path, g_e2e):
     assert C.auto_load_model(str(tmp_path / "empty"), model2, opt2) == 0
 
 
+def test_reference_way_optimizer_layout(g_e2e):
+    """create_optimizer builds what the reference trainer builds (utils/optim_factory.py:136-150): two groups, trainable
+    parameters only (the frozen sin-cos pos_emb are NOT optimizer parameters), weight decay everywhere."""
+    from incomplete_multimodal_fusion_amd.pretrain import NoWeightingStrategy, UncertaintyWeightingStrategy, create_optimizer
+    model = _tiny(g_e2e)
+    n_train = sum(1 for p in model.parameters() if p.requires_grad)
+    n_all = sum(1 for _ in model.parameters())
+    assert n_all > n_train                                                   # pos_emb parameters are frozen
+    sd = create_optimizer(model, NoWeightingStrategy()).state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [n_train, 0]
+    sd = create_optimizer(model, UncertaintyWeightingStrategy(["s1", "s2", "dem"]), balancer_lr_scale=2.0).state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [n_train, 1]
+    assert sd["param_groups"][1]["lr_scale"] == 2.0 and sd["param_groups"][0]["weight_decay"] == 0.05
+
+
 @pytest.mark.gpu
 def test_flat_engine_optimizer_round_trip(tmp_path, g_e2e):
-    """FlatAdamW state is written in torch.optim.AdamW layout and both optimizers can resume from it."""
+    """FlatAdamW state is written in the REFERENCE trainer's optimizer layout (two groups over the trainable parameters,
+    pos_emb excluded) and exchanges files with an optimizer built the reference way, in both directions."""
     from incomplete_multimodal_fusion_amd import checkpoint as C
     from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import NoWeightingStrategy, create_optimizer
     model = _tiny(g_e2e).to("cuda")
     opt = FlatAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, exclude=model.never_used_parameters())
     for _ in range(2):
@@ -56,11 +73,23 @@ def test_flat_engine_optimizer_round_trip(tmp_path, g_e2e):
             p.grad = torch.randn_like(p)
             opt._on_grad(p)
         opt.step()
-    C.save_model(str(tmp_path), 4, model, opt)
-    ref = torch.optim.AdamW(model.parameters(), lr=9.0)
+    C.save_model(str(tmp_path), 4, model, opt, loss_balancer=NoWeightingStrategy())
+    ck = torch.load(os.path.join(tmp_path, "checkpoint-4.pth"), weights_only=False)
+    n_train = sum(1 for p in model.parameters() if p.requires_grad)
+    assert [len(g["params"]) for g in ck["optimizer"]["param_groups"]] == [n_train, 0]
+    # (1) engine file -> reference-way torch optimizer (torch's own load_state_dict: group sizes / shapes must match)
     model_t = _tiny(g_e2e).to("cuda")
-    ref_t = torch.optim.AdamW(model_t.parameters(), lr=9.0)
+    ref_t = create_optimizer(model_t, NoWeightingStrategy(), lr=9.0)
     assert C.auto_load_model(str(tmp_path), model_t, ref_t, map_location="cuda") == 5
+    st = ref_t.state_dict()["state"]
+    assert len(st) == len(opt.params) and all(float(v["step"]) == 2.0 for v in st.values())
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    by_name = dict(model.named_parameters())
+    for i, v in st.items():
+        p = by_name[names[i]]
+        o = opt.offsets[id(p)]
+        assert torch.equal(v["exp_avg"], opt.exp_avg[o:o + p.numel()].view_as(p)), names[i]
+    # (2) engine file -> engine
     model_f = _tiny(g_e2e).to("cuda")
     opt_f = FlatAdamW(model_f.parameters(), lr=9.0, betas=(0.9, 0.95), weight_decay=0.0, exclude=model_f.never_used_parameters())
     assert C.auto_load_model(str(tmp_path), model_f, opt_f, map_location="cuda") == 5
@@ -68,5 +97,30 @@ def test_flat_engine_optimizer_round_trip(tmp_path, g_e2e):
     assert torch.equal(opt_f.exp_avg, opt.exp_avg) and torch.equal(opt_f.exp_avg_sq, opt.exp_avg_sq)
     assert torch.equal(opt_f.master, opt.master)
     assert torch.equal(opt_f.shadow, opt_f.master.to(torch.bfloat16))
-    st = ref_t.state_dict()["state"]
-    assert len(st) == len(opt.params) and all(float(v["step"]) == 2.0 for v in st.values())
+    # (3) reference-way torch optimizer file -> engine: step both once more on the same gradients, weights must agree
+    for p in model_t.parameters():
+        p.grad = None
+    g = torch.Generator(device="cuda").manual_seed(5)
+    grads = {n: torch.randn(p.shape, device="cuda", generator=g) for n, p in model_t.named_parameters() if p.requires_grad}
+    unused = {id(p) for p in model_t.never_used_parameters()}
+    for n, p in model_t.named_parameters():
+        if p.requires_grad and id(p) not in unused:
+            p.grad = grads[n].clone()
+    for grp in ref_t.param_groups:
+        grp["lr"] = 1e-3
+    ref_t.step()
+    sub = tmp_path / "ref"
+    C.save_model(str(sub), 7, model_t, ref_t, loss_balancer=NoWeightingStrategy())
+    model_g = _tiny(g_e2e).to("cuda")
+    opt_g = FlatAdamW(model_g.parameters(), lr=1.0, betas=(0.9, 0.95), weight_decay=0.0, exclude=model_g.never_used_parameters())
+    assert C.auto_load_model(str(sub), model_g, opt_g, map_location="cuda") == 8
+    assert opt_g.steps == 3
+    opt_g.zero_grad()
+    for n, p in model_g.named_parameters():
+        if id(p) in opt_g.offsets:
+            p.grad = grads[n].clone()
+            opt_g._on_grad(p)
+    opt_g.step()
+    ref_t.step()                                                             # same gradients again on the torch side
+    for (n, a), (_, b) in zip(model_g.named_parameters(), model_t.named_parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=3e-6), n

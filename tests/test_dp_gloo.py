@@ -80,3 +80,101 @@ def test_two_rank_gloo_bucketed_allreduce_matches_single_process():
                 if n == "unused":
                     continue
                 assert torch.allclose(torch.tensor(step_grads[n]), p.grad, atol=1e-6), (rank, n)
+
+
+class Branchy(torch.nn.Module):
+    """The set of parameters that receive a gradient depends on `use_side` (like ViTBaseline's random modality subset)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(16, 32)
+        self.side = torch.nn.Linear(16, 32)
+        self.c = torch.nn.Linear(32, 4)
+
+    def forward(self, x, use_side):
+        h = self.a(x)
+        if use_side:
+            h = h + self.side(x)
+        return self.c(torch.relu(h))
+
+
+# (step, rank) -> does this rank's forward use the side branch?  step 0: nobody; step 1: rank 1 only; step 2: both
+_SIDE = {(0, 0): False, (0, 1): False, (1, 0): False, (1, 1): True, (2, 0): True, (2, 1): True}
+
+
+def _worker_dynamic(rank, world, port, q, static):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from incomplete_multimodal_fusion_amd import dp
+    assert dp.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    net = Branchy()
+    red = dp.GradAllReducer(net.parameters(), bucket_bytes=1500, static_unused=static)
+    torch.manual_seed(100)
+    X = torch.randn(8, 16); Y = torch.randn(8, 4)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    res, err = [], None
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        red.prepare()
+        loss = ((net(xs, _SIDE[(step, rank)]) - ys) ** 2).mean()
+        try:
+            loss.backward()
+            red.finish()
+        except RuntimeError as e:
+            err = str(e)
+            break
+        res.append({n: (None if p.grad is None else p.grad.tolist()) for n, p in net.named_parameters()})
+    q.put((rank, res, err))
+    if err is None:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_dynamic(static):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dynamic, args=(r, 2, port, q, static)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+    return out
+
+
+@pytest.mark.timeout(120)
+def test_used_parameter_set_changes_between_steps_and_ranks():
+    """static_unused=False: every step equals the average of the two ranks' local gradients (zeros where a rank did not
+    use a parameter), and a parameter used on ANY rank gets its gradient on EVERY rank (replicas stay in sync)."""
+    out = _run_dynamic(static=False)
+    for step in range(3):
+        locals_ = []
+        for rank in range(2):
+            torch.manual_seed(0)
+            net = Branchy()
+            torch.manual_seed(100)
+            X = torch.randn(8, 16); Y = torch.randn(8, 4)
+            xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+            ((net(xs, _SIDE[(step, rank)]) - ys) ** 2).mean().backward()
+            locals_.append({n: p.grad for n, p in net.named_parameters()})
+        for rank, res, err in out:
+            assert err is None
+            for n in locals_[0]:
+                gs = [l[n] for l in locals_]
+                got = res[step][n]
+                if all(g is None for g in gs):
+                    assert got is None, (step, rank, n)                  # unused everywhere: stays without a gradient
+                    continue
+                want = sum(torch.zeros_like(next(x for x in gs if x is not None)) if g is None else g for g in gs) / 2
+                assert got is not None, (step, rank, n)
+                assert torch.allclose(torch.tensor(got), want, atol=1e-6), (step, rank, n)
+
+
+@pytest.mark.timeout(120)
+def test_static_unused_raises_when_an_excluded_parameter_gets_a_gradient():
+    out = _run_dynamic(static=True)
+    errs = [err for _, _, err in out]
+    assert any(e and "static_unused=False" in e for e in errs), errs
