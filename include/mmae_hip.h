@@ -45,11 +45,6 @@ int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
                  const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                  int empty_mode, void* stream);
 
-/* test hook: 1 routes bf16 through the generic dtype-templated kernels instead of the bf16 fast path (mha_bf16.hip). */
-int mmae_mha_set_generic_bf16(int on);
-/* tuning hook: kernel variant of the bf16 fast path (0 = default; see mha_bf16.hip). */
-int mmae_mha_set_variant(int v);
-
 /* ---- modality attention of Block_Fusion (DSI-MM/zorro_utils.py:252-256 on MM/multimae_crossattn.py:454-462) ---------
  * For each of the B*P (sample, patch) rows: the fusion query (row of q) attends `ns` = M+1 key/value rows of kv
  * (kv[row] = [K (inner) | V (inner)]) named by slot_row (B*P, ns).  Rows < shared_base are token rows, each used by
@@ -84,6 +79,12 @@ int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout,
 /* ---- GELU of Mlp (DSI-MM/zorro_utils.py:141-143, MM/multimae_utils.py:148-150) -------------------------------------- */
 int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* stream);
 int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, void* dx, void* stream);
+
+/* ---- column sums: out[c] = sum_r x[r*ld + c] in fp32, deterministic two-stage (bias gradients = autograd of the `+ bias` of
+ *      nn.Linear in the decoders / Mlp heads, MM/multimae_utils.py:138-182, MM/output_adapters_simple.py:166-181).
+ *      cols and ld multiples of 8 (bf16) / 4 (fp32); ws: mmae_colsum_ws_floats(rows, cols) floats. */
+long mmae_colsum_ws_floats(long rows, int cols);
+int mmae_colsum(int dtype, long rows, int cols, const void* x, long ld, float* out, float* ws, void* stream);
 
 /* ---- row gather / scatter (token selection MM/multimae_crossattn.py:402-407, :531-541; pos-emb lookup) ------------- */
 int mmae_gather_rows(int dtype, long rows, int W, const void* src, long src_stride, const int* idx, void* out,

@@ -10,6 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmae_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmae_hip.h")
+INTERNAL_HEADER_PATH = os.path.join(_HERE, "csrc", "mmae_internal.h")      # test / tuning entry points, not the product ABI
 
 F32, BF16 = 0, 1
 
@@ -52,7 +53,9 @@ def lib():
                 "libmmae_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C incomplete_multimodal_fusion_amd/csrc`. There is no CPU / eager fallback." % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
-        for name, (ret, argtypes) in parse_header().items():
+        protos = dict(parse_header())
+        protos.update(parse_header(INTERNAL_HEADER_PATH))
+        for name, (ret, argtypes) in protos.items():
             fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = ret
             fn.argtypes = argtypes

@@ -27,6 +27,7 @@
 //               sweeping the query tiles that may attend them; dK^T / dV^T accumulate in registers, no atomics.
 #include "common.hpp"
 #include "mmae_hip.h"
+#include "mmae_internal.h"
 
 #include "mha_common.hpp"
 
@@ -435,10 +436,6 @@ template <typename T, int DH> static int launch_bwd(MhaDesc d, int max_q_tiles, 
     return MMAE_OK;
 }
 
-// test hook: 1 = run bf16 through the generic (dtype-templated) kernels instead of the bf16 fast path
-static int g_use_generic_bf16 = 0;
-extern "C" int mmae_mha_set_generic_bf16(int on) { g_use_generic_bf16 = on; return 0; }
-
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int check_common(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
@@ -452,10 +449,10 @@ static int check_common(int dtype, int head_dim, int B, int H, int nseg, const v
     return MMAE_OK;
 }
 
-extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+extern "C" int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             void* out, float* lse, long q_stride, long k_stride, long v_stride, long o_stride,
                             long q_rows_total, const int* q_seg_start, const int* q_seg_len, const int* k_seg_start,
-                            const int* k_seg_len, int max_q_rows, float scale, int empty_mode, void* stream) {
+                            const int* k_seg_len, int max_q_rows, float scale, int empty_mode, int variant, void* stream) {
     int rc = check_common(dtype, head_dim, B, H, nseg, q, k, v, q_stride, k_stride, v_stride, q_seg_start, q_seg_len,
                           k_seg_start, k_seg_len);
     if (rc) return rc;
@@ -467,16 +464,25 @@ extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, con
     d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_tiles = max_q_rows / 64 + nseg;
     d.scale = scale; d.empty_mode = empty_mode;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MMAE_BF16) return g_use_generic_bf16 ? (head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st)) : mha_bf16_fwd(d, head_dim, st);
+    if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st)) : mha_bf16_fwd(d, head_dim, variant, st);
     return head_dim == 64 ? launch_fwd<float, 64>(d, st) : launch_fwd<float, 32>(d, st);
 }
 
-extern "C" int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                            void* out, float* lse, long q_stride, long k_stride, long v_stride, long o_stride,
+                            long q_rows_total, const int* q_seg_start, const int* q_seg_len, const int* k_seg_start,
+                            const int* k_seg_len, int max_q_rows, float scale, int empty_mode, void* stream) {
+    return mmae_mha_fwd_variant(dtype, head_dim, B, H, nseg, q, k, v, out, lse, q_stride, k_stride, v_stride, o_stride,
+                                q_rows_total, q_seg_start, q_seg_len, k_seg_start, k_seg_len, max_q_rows, scale, empty_mode,
+                                0, stream);
+}
+
+extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk,
                             void* dv, long q_stride, long k_stride, long v_stride, long o_stride, long do_stride,
                             long dq_stride, long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start,
                             const int* q_seg_len, const int* k_seg_start, const int* k_seg_len, int max_q_rows,
-                            int max_k_rows, float scale, int empty_mode, void* stream) {
+                            int max_k_rows, float scale, int empty_mode, int variant, void* stream) {
     int rc = check_common(dtype, head_dim, B, H, nseg, q, k, v, q_stride, k_stride, v_stride, q_seg_start, q_seg_len,
                           k_seg_start, k_seg_len);
     if (rc) return rc;
@@ -494,6 +500,17 @@ extern "C" int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, con
     d.scale = scale; d.empty_mode = empty_mode;
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MMAE_BF16) return g_use_generic_bf16 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, st);
+    if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, variant, st);
     return head_dim == 64 ? launch_bwd<float, 64>(d, mq, mk, st) : launch_bwd<float, 32>(d, mq, mk, st);
+}
+
+extern "C" int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                            const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk,
+                            void* dv, long q_stride, long k_stride, long v_stride, long o_stride, long do_stride,
+                            long dq_stride, long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start,
+                            const int* q_seg_len, const int* k_seg_start, const int* k_seg_len, int max_q_rows,
+                            int max_k_rows, float scale, int empty_mode, void* stream) {
+    return mmae_mha_bwd_variant(dtype, head_dim, B, H, nseg, q, k, v, out, dout, lse, delta_ws, dq, dk, dv, q_stride, k_stride,
+                                v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride, q_rows_total, q_seg_start,
+                                q_seg_len, k_seg_start, k_seg_len, max_q_rows, max_k_rows, scale, empty_mode, 0, stream);
 }

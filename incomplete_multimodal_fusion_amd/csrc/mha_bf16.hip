@@ -619,10 +619,8 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
-static int g_variant = 0;   // tuning hook for tools/bench_attn.py: forward tiling (0 default, 1, 8: see mha_bf16_fwd)
-extern "C" int mmae_mha_set_variant(int v) { g_variant = v; return 0; }
-
-int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st) {
+// `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
+int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant == 0) {                  // default: 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
@@ -639,7 +637,7 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st) {
     return MMAE_OK;
 }
 
-int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, hipStream_t st) {
+int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int g_variant, hipStream_t st) {
     if (max_q_tiles > MAXT || max_k_tiles > MAXT) return MMAE_ERR_ARG;
     d.max_tiles = max_q_tiles;
     if (head_dim == 64 && g_variant == 2) {                  // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default

@@ -51,5 +51,5 @@ __device__ __forceinline__ TileSel select_tile(const int* len, int nseg, int t) 
 
 
 // bf16 fast path (mha_bf16.hip)
-int mha_bf16_fwd(const MhaDesc& d, int head_dim, hipStream_t st);
-int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, hipStream_t st);
+int mha_bf16_fwd(const MhaDesc& d, int head_dim, int variant, hipStream_t st);
+int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int variant, hipStream_t st);

@@ -1,0 +1,27 @@
+/* mmae_internal.h -- NOT part of the product ABI (include/mmae_hip.h).  Test / tuning entry points of libmmae_hip.so:
+ * the attention launchers with the kernel variant as a PER-CALL argument (no process-global state, so concurrent streams
+ * and threads cannot change each other's kernel).  Consumers: tests/ (generic-vs-fast-path agreement) and
+ * tools/bench_attn.py (A/B of tilings inside one process).
+ *
+ * variant  0  what mmae_mha_fwd / mmae_mha_bwd run
+ *         -1  bf16 through the generic dtype-templated kernels of mha.hip instead of the bf16 fast path
+ *        > 0  alternative tilings of the bf16 fast path (see mha_bf16.hip: mha_bf16_fwd / mha_bf16_bwd) */
+#ifndef MMAE_INTERNAL_H
+#define MMAE_INTERNAL_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v, void* out,
+                         float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
+                         const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
+                         int max_q_rows, float scale, int empty_mode, int variant, void* stream);
+int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                         const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                         long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,
+                         long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
+                         const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
+                         int empty_mode, int variant, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

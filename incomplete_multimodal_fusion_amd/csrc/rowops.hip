@@ -541,3 +541,64 @@ extern "C" int mmae_scatter_rows(int dtype, long rows, int W, const void* src, l
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------ column sums (bias gradients)
+// out[c] = sum_r x[r, c] in fp32 (autograd of the `+ bias` of nn.Linear: decoder qkv/proj/fc1/fc2, proj_context, out_proj,
+// Mlp -- MM/multimae_utils.py:138-182, MM/output_adapters_simple.py:166-181).  Stage 1: every block sums a strip of rows,
+// 8 (bf16) / 4 (fp32) columns per lane, 16-byte loads; stage 2: the partial rows are added in fixed order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long rows, int cols, long ld,
+                                                             int rows_per_block, float* __restrict__ ws) {
+    constexpr int V = 16 / sizeof(T);
+    const int cg = cols / V;                                  // column groups (cols % V == 0)
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    for (int g0 = threadIdx.x; g0 < cg; g0 += 256) {
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            if (sizeof(T) == 2) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(x) + r * ld + (long)g0 * V);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += (float)v[j];
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ld + (long)g0 * V);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) ws[(long)blockIdx.x * cols + (long)g0 * V + j] = acc[j];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int nblk, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += ws[(long)b * cols + c]; s1 += ws[(long)(b + 1) * cols + c];
+        s2 += ws[(long)(b + 2) * cols + c]; s3 += ws[(long)(b + 3) * cols + c];
+    }
+    for (; b < nblk; ++b) s0 += ws[(long)b * cols + c];
+    out[c] = (s0 + s1) + (s2 + s3);
+}
+
+static int colsum_blocks(long rows) { long b = (rows + 63) / 64; if (b > 1024) b = 1024; if (b < 1) b = 1; return (int)b; }
+extern "C" long mmae_colsum_ws_floats(long rows, int cols) { return rows < 0 || cols <= 0 ? MMAE_ERR_ARG : (long)colsum_blocks(rows) * cols; }
+extern "C" int mmae_colsum(int dtype, long rows, int cols, const void* x, long ld, float* out, float* ws, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || cols <= 0 || !x || !out || !ws) return MMAE_ERR_ARG;
+    const int V = dtype == MMAE_BF16 ? 8 : 4;
+    if ((cols % V) || (ld % V) || ld < cols || (reinterpret_cast<uintptr_t>(x) & 15)) return MMAE_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = colsum_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, rows, cols, ld, rpb, ws);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, rows, cols, ld, rpb, ws);
+    MMAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, ws, nb, cols, out);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}

@@ -200,9 +200,22 @@ class _Linear(torch.autograd.Function):
                     grads_written_in_place(ctx.ws)           # .grad = flat view; autograd gets None (no clone, no copy back)
             gb = None
             if bdt is not False and ctx.needs_input_grad[1]:
-                gb = g2.sum(0, dtype=torch.float32)
+                gb = colsum(g2)
                 gb = gb if gb.dtype == bdt else gb.to(bdt)
         return (gx, gb, None, *gws)
+
+
+def colsum(x2: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a row-major (rows, cols) matrix (bias gradients); deterministic summation order."""
+    rows, cols = x2.shape
+    V = 8 if x2.dtype == torch.bfloat16 else 4
+    if x2.dtype not in (torch.bfloat16, torch.float32) or cols % V or x2.stride(0) % V or x2.stride(1) != 1 or \
+            x2.data_ptr() % 16 or rows == 0:
+        return x2.sum(0, dtype=torch.float32)          # odd widths (e.g. a 9-class head x 8x8 patch is fine; 85-wide is not)
+    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    ws = torch.empty(_lib.lib().mmae_colsum_ws_floats(rows, cols), dtype=torch.float32, device=x2.device)
+    call("mmae_colsum", dt(x2), rows, cols, ptr(x2), x2.stride(0), ptr(out), ptr(ws), stream())
+    return out
 
 
 class _NullCtx:
@@ -289,7 +302,7 @@ def linear(x, weight, bias=None, side_wgrad=False, once=False):
 # ------------------------------------------------------------------------------------------------ attention
 class _MHA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qt, kvt, qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode):
+    def forward(ctx, qt, kvt, qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, variant=0):
         I = H * dh
         same = kvt is None
         kv = qt if same else kvt
@@ -298,8 +311,9 @@ class _MHA(torch.autograd.Function):
         new = torch.empty if qseg.covers_all else torch.zeros
         out = new(qt.shape[0], I, dtype=qt.dtype, device=qt.device)
         lse = new(H, qt.shape[0], dtype=torch.float32, device=qt.device)
-        assert kseg.max_rows // 64 + kseg.nseg <= 80 and qseg.max_rows // 64 + qseg.nseg <= 80, \
-            "at most ~4.8k rows per sample in one attention call"
+        if kseg.max_rows // 64 + kseg.nseg > 80 or qseg.max_rows // 64 + qseg.nseg > 80:
+            raise _lib.MmaeLibraryError("masked attention: at most 80 64-row tiles (~4.8k rows) per sample in one call "
+                                        "(MAXT in csrc/mha_bf16.hip); got %d query / %d key rows" % (qseg.max_rows, kseg.max_rows))
         es = qt.element_size()
         # bench.py's roofline_attention: every launch of the dh = 64 instance (encoder blocks, pooling), so the event
         # average is the same population as that kernel's row in the rocprofv3 summary
@@ -310,22 +324,22 @@ class _MHA(torch.autograd.Function):
             _TIMER.add_flops(pairs.double() * (4.0 * dh * H))
             ev0, ev1 = _TIMER.bracket()
             ev0.record()
-        call("mmae_mha_fwd", dt(qt), dh, qseg.B, H, qseg.nseg,
+        call("mmae_mha_fwd_variant" if variant else "mmae_mha_fwd", dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
              ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(lse),
              qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), qt.shape[0],
              ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length), qseg.max_rows, scale, empty_mode,
-             stream())
+             *((variant,) if variant else ()), stream())
         if timed:
             ev1.record()
         ctx.save_for_backward(qt, kv, out, lse)
-        ctx.cfg = (qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same)
+        ctx.cfg = (qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same, variant)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         qt, kv, out, lse = ctx.saved_tensors
-        qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same = ctx.cfg
+        qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, same, variant = ctx.cfg
         gout = _c(gout)
         I = H * dh
         # every row of q / kv belongs to exactly one segment, and the q, k, v column slices are written completely;
@@ -337,21 +351,22 @@ class _MHA(torch.autograd.Function):
         gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
         delta = torch.empty_like(lse)
         es = qt.element_size()
-        call("mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
+        call("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
              ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(gout), ptr(lse), ptr(delta),
              ctypes.c_void_p(gq.data_ptr() + qcol * es), ctypes.c_void_p(gkv.data_ptr() + kcol * es),
              ctypes.c_void_p(gkv.data_ptr() + vcol * es),
              qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), gout.stride(0), gq.stride(0), gkv.stride(0),
              gkv.stride(0), qt.shape[0], ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length),
-             qseg.max_rows, kseg.max_rows, scale, empty_mode, stream())
-        return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None
+             qseg.max_rows, kseg.max_rows, scale, empty_mode, *((variant,) if variant else ()), stream())
+        return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None, None
 
 
-def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv") -> torch.Tensor:
-    """Self attention on a fused projection output qkv (rows, 3*H*dh) laid out [q | k | v] column blocks."""
+def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv", variant: int = 0) -> torch.Tensor:
+    """Self attention on a fused projection output qkv (rows, 3*H*dh) laid out [q | k | v] column blocks.
+    variant != 0: test / tuning kernels through csrc/mmae_internal.h (per call, no global state)."""
     I = H * dh
-    return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0)
+    return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0, variant)
 
 
 def mha_cross(q: torch.Tensor, kv: torch.Tensor, H: int, dh: int, qseg: Segments, kseg: Segments, scale: float,

@@ -147,3 +147,130 @@ def test_transposed_shadow_and_splitk_sum():
         for s in range(S):
             ref += part[s].float()
         assert torch.equal(out, ref)
+
+
+def _pair(shapes, **kw):
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    ref = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    o_mine = FlatAdamW(mine, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    return ref, mine, o_ref, o_mine
+
+
+def _feed(ref, mine, o_ref, o_mine, grads):
+    o_ref.zero_grad(); o_mine.zero_grad()
+    for p, q, g in zip(ref, mine, grads):
+        if g is None:
+            continue
+        p.grad = g.clone()
+        (q * g).sum().backward()
+
+
+def test_device_side_clip_matches_torch_clip_grad_norm():
+    """clip_grad of NativeScaler (native_scaler.py:23-26): torch.nn.utils.clip_grad_norm_ + AdamW, without a host sync."""
+    torch.manual_seed(10)
+    shapes = [(256, 768), (768,), (85, 32), (7,)]
+    ref, mine, o_ref, o_mine = _pair(shapes)
+    for step, scale in enumerate([1.0, 30.0, 0.01, 5.0]):             # norms above and below max_norm = 3
+        grads = [scale * torch.randn_like(p) for p in ref]
+        _feed(ref, mine, o_ref, o_mine, grads)
+        norm = torch.nn.utils.clip_grad_norm_(ref, 3.0)
+        o_ref.step()
+        o_mine.step(clip_grad=3.0)
+        close(o_mine.last_grad_norm(), norm, 1e-5, "norm step %d" % step)
+        assert not o_mine.last_step_skipped()
+        for p, q in zip(ref, mine):
+            close(q, p, 3e-6, "param step %d" % step)
+
+
+def test_device_side_skip_and_non_finite_guard_match_not_stepping():
+    """skip_grad (native_scaler.py:27-32) and GradScaler's found-inf rule: the optimizer is NOT stepped -- weights, moments
+    and the step count used for bias correction stay; later steps agree with a torch optimizer that skipped the same ones."""
+    torch.manual_seed(11)
+    shapes = [(128, 96), (96,), (33, 8)]
+    ref, mine, o_ref, o_mine = _pair(shapes)
+    plan = [("ok", 1.0), ("big", 1e4), ("ok", 1.0), ("nan", 1.0), ("inf", 1.0), ("ok", 1.0)]
+    for step, (kind, scale) in enumerate(plan):
+        grads = [scale * torch.randn_like(p) for p in ref]
+        if kind == "nan":
+            grads[0][3, 5] = float("nan")
+        if kind == "inf":
+            grads[2][0, 0] = float("inf")
+        _feed(ref, mine, o_ref, o_mine, grads)
+        before = [q.detach().clone() for q in mine]
+        if kind == "ok":
+            o_ref.step()
+        o_mine.step(skip_grad=50.0, check_finite=True)
+        assert o_mine.last_step_skipped() == (kind != "ok"), (step, kind)
+        if kind != "ok":
+            for q, b in zip(mine, before):
+                assert torch.equal(q, b), "a skipped step must not touch the weights"
+        for p, q in zip(ref, mine):
+            close(q, p, 3e-6, "param step %d (%s)" % (step, kind))
+            assert torch.isfinite(q).all()
+    assert o_mine.skipped_steps() == 3
+    assert all(o_mine.param_step(q) == 3 for q in mine)
+    for q, p in zip(mine, ref):                                      # torch's per-parameter step count agrees
+        assert float(o_ref.state[p]["step"]) == 3.0
+
+
+def test_parameters_without_gradient_are_left_alone_like_torch_adamw():
+    """torch.optim.AdamW skips `p.grad is None`: no weight decay, no moment decay, its own step count (the downstream
+    backbone's per-forward modality subsets do this to the patch-embedding weights)."""
+    torch.manual_seed(12)
+    shapes = [(64, 48), (48,), (40, 16), (16,), (9, 8)]
+    ref, mine, o_ref, o_mine = _pair(shapes)
+    present = [[1, 1, 1, 1, 1], [1, 0, 1, 1, 0], [0, 0, 1, 1, 1], [1, 1, 0, 1, 1], [1, 1, 1, 1, 1]]
+    for step, pres in enumerate(present):
+        grads = [torch.randn_like(p) if on else None for p, on in zip(ref, pres)]
+        _feed(ref, mine, o_ref, o_mine, grads)
+        o_ref.step(); o_mine.step()
+        for i, (p, q) in enumerate(zip(ref, mine)):
+            close(q, p, 3e-6, "param %d step %d" % (i, step))
+            assert torch.equal(q._mmae_shadow, q.detach().to(torch.bfloat16))
+    for i, (p, q) in enumerate(zip(ref, mine)):
+        assert o_mine.param_step(q) == int(float(o_ref.state[p]["step"])) == sum(pr[i] for pr in present)
+
+
+def test_second_backward_before_zero_grad_raises_for_in_place_gradients():
+    """Weight gradients that producers write straight into the flat buffer are assigned, not accumulated: a second backward
+    before zero_grad() must fail loudly instead of silently dropping the first gradient."""
+    from incomplete_multimodal_fusion_amd import ops
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    torch.manual_seed(13)
+    w = torch.nn.Parameter(torch.randn(256, 128, device=DEV))
+    opt = FlatAdamW([w], lr=1e-3)
+    x = torch.randn(64, 128, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    opt.zero_grad()
+    ops.linear(x, w, once=True).float().sum().backward()
+    with pytest.raises(RuntimeError, match="one backward per zero_grad"):
+        ops.linear(x, w, once=True).float().sum().backward()
+    opt.zero_grad()
+    ops.linear(x, w, once=True).float().sum().backward()             # fine again after zero_grad()
+    opt.step()
+
+
+def test_pretrain_step_clip_and_finite_guard():
+    """PretrainStep wires clip_grad / the non-finite guard to the engine: a NaN input batch leaves the model untouched."""
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep, get_model
+    torch.manual_seed(14)
+    model = get_model("tiny", input_size=64, decoder_dim=64, decoder_depth=1, decoder_num_heads=2)
+    model.depth = 2; model.blocks = model.blocks[:2]; model.fus_blocks = model.fus_blocks[:2]
+    model.to(DEV).train()
+    opt = FlatAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, exclude=model.never_used_parameters())
+    step = PretrainStep(model, opt, 24, autocast=True, clip_grad=0.5)
+    B = 4
+    x = {"s1": torch.randn(B, 1, 64, 64, device=DEV), "s2": torch.randn(B, 3, 64, 64, device=DEV),
+         "dem": torch.randn(B, 1, 64, 64, device=DEV)}
+    step(x)
+    assert not opt.last_step_skipped() and float(opt.last_grad_norm()) > 0
+    before = opt.master.clone()
+    bad = {k: v.clone() for k, v in x.items()}
+    bad["s2"][1, 2, 5, 5] = float("nan")
+    step(bad)
+    assert opt.last_step_skipped()
+    assert torch.equal(opt.master, before) and torch.isfinite(opt.master).all()
+    step(x)
+    assert not opt.last_step_skipped() and not torch.equal(opt.master, before)

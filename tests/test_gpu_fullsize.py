@@ -11,7 +11,6 @@ import torch
 
 from oracle import mmae_oracle as O
 from tests.test_cabi_symbols import build_model
-from tests.test_gpu_e2e import grad_close, native_step
 from tests.test_gpu_kernels import DEV, close
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +33,10 @@ def _vitb(seed):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_vitb_full_step_vs_oracle(mode):
+    """Every output, loss and parameter gradient of one ViT-B step.  fp32: 1e-3 (gradients 2e-3).  bf16: 1e-2, or -- where a
+    tensor exceeds it -- within 1.5x the error the REFERENCE arithmetic itself shows in bf16 on the same weights and inputs
+    (the oracle under CPU bf16 autocast; tests/parity.py).  No hand-picked relaxation."""
+    from tests import parity
     model = _vitb(21)
     B, P, N = 2, 256, 384
     x = {d: torch.randn(B, c, 256, 256) for d, c in CHANNELS}
@@ -43,33 +46,13 @@ def test_vitb_full_step_vs_oracle(mode):
         row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
         masks[d] = row[None].repeat(B, 1)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("pos_emb") and not k.endswith("beta"))
-         for k, v in state.items()}
-    out_r, (tl_r, lc_r, loss_r) = O.train_step_loss(p, x, masks, N, VITB["heads"], VITB["decoder_heads"], 16)
-    loss_r.backward()
-    model.to(DEV).train()
+    ref = parity.oracle_step(state, x, masks, N, VITB["heads"], VITB["decoder_heads"])
     autocast = mode == "bf16"
-    tol = 1e-3 if not autocast else 1e-2                # north_star: fp32 1e-3, bf16 1e-2 (max-abs relative to max|ref|)
-    act = tol * (4 if autocast else 1)                  # activations after 12 bf16 layers: 4e-2 of the dynamic range
+    anchor = parity.oracle_step(state, x, masks, N, VITB["heads"], VITB["decoder_heads"], bf16=True) if autocast else None
+    model.to(DEV).train()
     xd = {k: v.to(DEV) for k, v in x.items()}; md = {k: v.to(DEV) for k, v in masks.items()}
-    out, tl, lc, loss = native_step(model, xd, md, N, True, autocast)
-    for d in O.DOMAINS:
-        close(out[0][d].image(), out_r[0][d], act, "pred " + d)
-        close(tl[d], tl_r[d], tol, "loss " + d)
-    close(out[2], out_r[2], act, "pooled"); close(out[3], out_r[3], act, "ori"); close(out[4], out_r[4], act, "fusion")
-    close(lc, lc_r, tol, "contra"); close(loss, loss_r, tol, "loss")
-    loss.backward()
-    bad = []
-    for n, prm in model.named_parameters():
-        ref = p[n].grad
-        if ref is None:
-            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
-            continue
-        try:
-            grad_close(prm.grad, ref, tol * 2, autocast, "grad " + n)
-        except AssertionError as e:
-            bad.append(str(e))
-    assert not bad, (len(bad), bad[:8])
+    got = parity.native_step_flat(model, xd, md, N, autocast)
+    parity.compare(got, ref, anchor, tol=1e-2 if autocast else 1e-3)
 
 
 def test_vitb_batch64_samples_are_independent_and_match_oracle():

@@ -421,11 +421,29 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     qkv = torch.randn(r, 3 * I, device=DEV).to(torch.bfloat16)
     g = torch.randn(r, I, device=DEV).to(torch.bfloat16)
     res = []
-    for generic in (1, 0):
-        _lib.lib().mmae_mha_set_generic_bf16(generic)
+    for variant in (-1, 0):                    # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path
         x = qkv.clone().requires_grad_()
-        out = ops.mha_self(x, H, dh, seg, dh ** -0.5)
+        out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)
         res.append((out.float(), x.grad.float()))
-    _lib.lib().mmae_mha_set_generic_bf16(0)
     close(res[1][0], res[0][0], 1e-2, "out"); close(res[1][1], res[0][1], 2e-2, "grads")
+
+
+def test_colsum_bias_gradient_kernel():
+    """mmae_colsum (bias gradients of the decoder / Mlp linears): fp32 sums of bf16 / fp32 matrices, strided rows, sizes that
+    do not fill a block; and the fallback for widths the 16-byte lanes cannot take."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(20)
+    for rows, cols, dt_ in ((65536, 768, torch.bfloat16), (1000, 256, torch.bfloat16), (37, 1024, torch.float32),
+                            (5000, 2304, torch.bfloat16), (64, 85, torch.float32)):
+        x = torch.randn(rows, cols, device=DEV).to(dt_)
+        close(ops.colsum(x), x.double().sum(0), 1e-5 if dt_ == torch.float32 else 2e-5, "colsum %s" % ((rows, cols, dt_),))
+    wide = torch.randn(512, 1024, device=DEV).to(torch.bfloat16)
+    view = wide[:, 256:768]                                             # row stride 1024, 512 columns
+    close(ops.colsum(view), view.double().sum(0), 2e-5, "strided colsum")
+    # through ops.linear: bias gradient == column sum of the upstream gradient
+    w = torch.nn.Parameter(torch.randn(256, 128, device=DEV)); b = torch.nn.Parameter(torch.zeros(256, device=DEV))
+    xin = torch.randn(4096, 128, device=DEV, dtype=torch.bfloat16)
+    g = torch.randn(4096, 256, device=DEV, dtype=torch.bfloat16)
+    ops.linear(xin, w, b).backward(g)
+    close(b.grad, g.double().sum(0), 2e-5, "bias grad")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of the masked attention kernels at the bench workload's shapes (one process, interleaved variants).
 
-    python tools/bench_attn.py [--B 256] [--variants 0,1,...]      variant = value passed to mmae_mha_set_variant()
+    python tools/bench_attn.py [--B 256] [--variants 0,1,...]      variant = per-call kernel variant (csrc/mmae_internal.h)
 """
 import argparse, sys, os, time
 import torch
@@ -38,17 +38,15 @@ g = torch.randn(B * S, I, device=dev).to(torch.bfloat16)
 pairs = sum(n * n for n in nm) + P * S
 flops_fwd = 4.0 * dh * H * pairs * B
 lib = _lib.lib()
-has_var = hasattr(lib, "mmae_mha_set_variant")
+has_var = True
 
 def run(variant):
-    if has_var:
-        lib.mmae_mha_set_variant(variant)
-    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variant)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
     for _ in range(a.iters):
-        out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+        out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variant)
     e[1].record()
     for _ in range(a.iters):
         qkv.grad = None
@@ -59,9 +57,9 @@ def run(variant):
 
 variants = [int(v) for v in a.variants.split(",")]
 if has_var and len(variants) > 1:       # agreement of every variant's forward output with the first one
-    lib.mmae_mha_set_variant(variants[0]); ref = ops.mha_self(qkv, H, dh, seg, dh ** -0.5).float()
+    ref = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variants[0]).float()
     for v in variants[1:]:
-        lib.mmae_mha_set_variant(v); o = ops.mha_self(qkv, H, dh, seg, dh ** -0.5).float()
+        o = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=v).float()
         print("variant %d vs %d: max |diff| %.3e" % (v, variants[0], float((o - ref).abs().max())), flush=True)
 res = {v: [] for v in variants}
 for r in range(a.rounds):
