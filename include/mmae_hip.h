@@ -24,6 +24,8 @@ extern "C" {
 #define MMAE_BF16 1
 #define MMAE_ABI_VERSION 1
 int mmae_abi_version(void);
+/* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
+int mmae_last_hip_error(void);
 
 /* ---- masked multi-head attention (DSI-MM/zorro_utils.py:181-193; decoder core MM/multimae_utils.py:172-179) ----------
  * Segment ("Zorro") mask as data: sample b has nseg query segments and nseg key segments (arrays (B, nseg), global row

@@ -71,7 +71,13 @@ _ERR = {-1: "invalid argument (MMAE_ERR_ARG)", -2: "HIP launch failed (MMAE_ERR_
 def call(name, *args):
     rc = getattr(lib(), name)(*args)
     if rc != 0:
-        raise MmaeLibraryError("%s failed: %s" % (name, _ERR.get(rc, rc)))
+        detail = ""
+        if rc == -2:
+            code = lib().mmae_last_hip_error()
+            fn = lib().mmae_hip_error_name
+            fn.restype, fn.argtypes = ctypes.c_char_p, [ctypes.c_int]
+            detail = " [hipError %d %s]" % (code, (fn(code) or b"?").decode())
+        raise MmaeLibraryError("%s failed: %s%s" % (name, _ERR.get(rc, rc), detail))
 
 
 def ptr(t):

@@ -77,10 +77,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Launch + check.  hipGetLastError() reports (and clears) the last error of ANY earlier runtime call of this thread -- e.g. a
+// benign hipErrorNotReady the host framework left behind after an event / stream query -- so the slot is cleared right before
+// the launch: MMAE_CHECK_LAUNCH() then sees this launch's own status only.  The code of a failed launch is kept per thread for
+// mmae_last_hip_error() (error reporting of the binding).
+extern thread_local int mmae_tls_last_hip_error;
+#define MMAE_LAUNCH(...)                                     \
+    do {                                                     \
+        (void)hipGetLastError();                             \
+        hipLaunchKernelGGL(__VA_ARGS__);                     \
+    } while (0)
 #define MMAE_CHECK_LAUNCH()                                  \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
-        if (e__ != hipSuccess) return MMAE_ERR_LAUNCH;       \
+        if (e__ != hipSuccess) { mmae_tls_last_hip_error = (int)e__; return MMAE_ERR_LAUNCH; } \
     } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -100,8 +100,8 @@ extern "C" int mmae_patchify_gather(int dtype_out, int nmod, const float* const*
     d.tok_mod = tok_mod; d.tok_patch = tok_patch; d.tokens_per_sample = tokens_per_sample;
     d.rows = (long)B * tokens_per_sample; d.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype_out == MMAE_BF16) hipLaunchKernelGGL((patchify_gather_kernel<bf16>), dim3(cdiv(d.rows, 4)), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((patchify_gather_kernel<float>), dim3(cdiv(d.rows, 4)), dim3(256), 0, st, d);
+    if (dtype_out == MMAE_BF16) MMAE_LAUNCH((patchify_gather_kernel<bf16>), dim3(cdiv(d.rows, 4)), dim3(256), 0, st, d);
+    else MMAE_LAUNCH((patchify_gather_kernel<float>), dim3(cdiv(d.rows, 4)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -113,8 +113,8 @@ extern "C" int mmae_unpatchify(int dtype_in, int B, int C, int H, int W, int pat
     const int P = (H / patch) * (W / patch);
     const long rows = (long)B * P;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype_in == MMAE_BF16) hipLaunchKernelGGL((unpatchify_kernel<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)tokens, image, rows, P, C, H, W, patch);
-    else hipLaunchKernelGGL((unpatchify_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)tokens, image, rows, P, C, H, W, patch);
+    if (dtype_in == MMAE_BF16) MMAE_LAUNCH((unpatchify_kernel<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)tokens, image, rows, P, C, H, W, patch);
+    else MMAE_LAUNCH((unpatchify_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)tokens, image, rows, P, C, H, W, patch);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -230,11 +230,11 @@ extern "C" int mmae_masked_loss_fwd(int pred_dtype, int pred_is_tokens, int kind
     LossDesc d{pred, target, mask, partial_ws, (long)B * P, P, C, H, W, patch, kind};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(d.rows, 4)), blk(256);
-    if (!pred_is_tokens) hipLaunchKernelGGL((masked_loss_partial_kernel<float, false>), grid, blk, 0, st, d);
-    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_loss_partial_kernel<bf16, true>), grid, blk, 0, st, d);
-    else hipLaunchKernelGGL((masked_loss_partial_kernel<float, true>), grid, blk, 0, st, d);
+    if (!pred_is_tokens) MMAE_LAUNCH((masked_loss_partial_kernel<float, false>), grid, blk, 0, st, d);
+    else if (pred_dtype == MMAE_BF16) MMAE_LAUNCH((masked_loss_partial_kernel<bf16, true>), grid, blk, 0, st, d);
+    else MMAE_LAUNCH((masked_loss_partial_kernel<float, true>), grid, blk, 0, st, d);
     MMAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(masked_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, mask, B, P, patch, den, stats);
+    MMAE_LAUNCH(masked_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, mask, B, P, patch, den, stats);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -249,9 +249,9 @@ extern "C" int mmae_masked_loss_bwd(int pred_dtype, int pred_is_tokens, int kind
     LossDesc d{pred, target, mask, nullptr, (long)B * P, P, C, H, W, patch, kind};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(d.rows, 4)), blk(256);
-    if (!pred_is_tokens) hipLaunchKernelGGL((masked_loss_bwd_kernel<float, false>), grid, blk, 0, st, d, den, stats, gloss, gpred);
-    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_loss_bwd_kernel<bf16, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
-    else hipLaunchKernelGGL((masked_loss_bwd_kernel<float, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    if (!pred_is_tokens) MMAE_LAUNCH((masked_loss_bwd_kernel<float, false>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else if (pred_dtype == MMAE_BF16) MMAE_LAUNCH((masked_loss_bwd_kernel<bf16, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else MMAE_LAUNCH((masked_loss_bwd_kernel<float, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -372,11 +372,11 @@ extern "C" int mmae_masked_ce_loss_fwd(int pred_dtype, int pred_is_tokens, int B
     CEDesc d{pred, target, mask, partial_ws, (long)B * P, P, C, H, W, patch, label_smoothing};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(d.rows, 4)), blk(256);
-    if (!pred_is_tokens) hipLaunchKernelGGL((masked_ce_partial_kernel<float, false>), grid, blk, 0, st, d);
-    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_ce_partial_kernel<bf16, true>), grid, blk, 0, st, d);
-    else hipLaunchKernelGGL((masked_ce_partial_kernel<float, true>), grid, blk, 0, st, d);
+    if (!pred_is_tokens) MMAE_LAUNCH((masked_ce_partial_kernel<float, false>), grid, blk, 0, st, d);
+    else if (pred_dtype == MMAE_BF16) MMAE_LAUNCH((masked_ce_partial_kernel<bf16, true>), grid, blk, 0, st, d);
+    else MMAE_LAUNCH((masked_ce_partial_kernel<float, true>), grid, blk, 0, st, d);
     MMAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(masked_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, mask, B, P, patch, den, stats);
+    MMAE_LAUNCH(masked_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, mask, B, P, patch, den, stats);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -392,9 +392,9 @@ extern "C" int mmae_masked_ce_loss_bwd(int pred_dtype, int pred_is_tokens, int B
     CEDesc d{pred, target, mask, nullptr, (long)B * P, P, C, H, W, patch, label_smoothing};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(d.rows, 4)), blk(256);
-    if (!pred_is_tokens) hipLaunchKernelGGL((masked_ce_bwd_kernel<float, false>), grid, blk, 0, st, d, den, stats, gloss, gpred);
-    else if (pred_dtype == MMAE_BF16) hipLaunchKernelGGL((masked_ce_bwd_kernel<bf16, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
-    else hipLaunchKernelGGL((masked_ce_bwd_kernel<float, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    if (!pred_is_tokens) MMAE_LAUNCH((masked_ce_bwd_kernel<float, false>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else if (pred_dtype == MMAE_BF16) MMAE_LAUNCH((masked_ce_bwd_kernel<bf16, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
+    else MMAE_LAUNCH((masked_ce_bwd_kernel<float, true>), grid, blk, 0, st, d, den, stats, gloss, gpred);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

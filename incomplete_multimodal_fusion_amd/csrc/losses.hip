@@ -130,9 +130,9 @@ extern "C" int mmae_dino_loss_fwd(int B, int D, const float* student, const floa
     if (B <= 0 || D <= 0 || (D % 4) || D > 1024 || !student || !teacher || !row_loss_ws || !loss) return MMAE_ERR_ARG;
     DinoDesc d{student, teacher, row_loss_ws, nullptr, nullptr, B, D, 1.f / student_temp, 1.f / teacher_temp};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dino_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, d);
+    MMAE_LAUNCH(dino_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, st, row_loss_ws, B, loss);
+    MMAE_LAUNCH(mean_rows_kernel, dim3(1), dim3(256), 0, st, row_loss_ws, B, loss);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -141,7 +141,7 @@ extern "C" int mmae_dino_loss_bwd(int B, int D, const float* student, const floa
                                   float teacher_temp, const float* gloss, float* gstudent, void* stream) {
     if (B <= 0 || D <= 0 || (D % 4) || D > 1024 || !student || !teacher || !gloss || !gstudent) return MMAE_ERR_ARG;
     DinoDesc d{student, teacher, nullptr, gloss, gstudent, B, D, 1.f / student_temp, 1.f / teacher_temp};
-    hipLaunchKernelGGL(dino_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d);
+    MMAE_LAUNCH(dino_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -247,7 +247,7 @@ extern "C" int mmae_hardneg_loss_fwd(int B, int D, const float* out_1, const flo
                                      float temperature, float* ws, float* loss, void* stream) {
     if (B <= 1 || D <= 0 || !out_1 || !out_2 || !ws || !loss) return MMAE_ERR_ARG;
     HnDesc d{out_1, out_2, loss, nullptr, nullptr, nullptr, ws, B, D, tau_plus, beta, temperature};
-    hipLaunchKernelGGL(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 0);
+    MMAE_LAUNCH(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 0);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -255,7 +255,7 @@ extern "C" int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const flo
                                      float temperature, float* ws, const float* gloss, float* g1, float* g2, void* stream) {
     if (B <= 1 || D <= 0 || !out_1 || !out_2 || !ws || !gloss || !g1 || !g2) return MMAE_ERR_ARG;
     HnDesc d{out_1, out_2, nullptr, gloss, g1, g2, ws, B, D, tau_plus, beta, temperature};
-    hipLaunchKernelGGL(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 1);
+    MMAE_LAUNCH(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 1);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

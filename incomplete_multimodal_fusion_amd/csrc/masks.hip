@@ -59,7 +59,7 @@ extern "C" int mmae_masks_from_draws(int R, int M, int P, int N, const float* di
     if (R <= 0 || M <= 0 || M > 7 || P <= 0 || P > 4096 || N < 0 || N > M * P) return MMAE_ERR_ARG;
     if (!dirichlet || !noise || !noise_all || !mask_all || !ids_keep || !ids_restore) return MMAE_ERR_ARG;
     DrawsDesc d{dirichlet, noise, noise_all, mask_all, ids_keep, ids_restore, R, M, P, N};
-    hipLaunchKernelGGL(masks_from_draws_kernel, dim3(R), dim3(256), (size_t)M * P * sizeof(float),
+    MMAE_LAUNCH(masks_from_draws_kernel, dim3(R), dim3(256), (size_t)M * P * sizeof(float),
                        reinterpret_cast<hipStream_t>(stream), d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -164,7 +164,7 @@ extern "C" int mmae_build_descriptors(int B, int R, int M, int P, int N, const l
     layout(B, M, P, N, off);
     if (hipMemsetAsync(desc + off[13], 0, 4 * sizeof(int), st) != hipSuccess) return MMAE_ERR_LAUNCH;
     BuildDesc d{mask_all, desc, B, R, M, P, N};
-    hipLaunchKernelGGL(build_descriptors_kernel, dim3(B), dim3(256), 0, st, d);
+    MMAE_LAUNCH(build_descriptors_kernel, dim3(B), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -418,7 +418,7 @@ template <typename T, int DH> static int launch_fwd(const MhaDesc& d, hipStream_
     const size_t lds = fwd_lds<T, DH>();
     if (set_lds(mha_fwd_kernel<T, DH>, lds)) return MMAE_ERR_LAUNCH;
     dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
-    hipLaunchKernelGGL((mha_fwd_kernel<T, DH>), grid, dim3(256), lds, st, d);
+    MMAE_LAUNCH((mha_fwd_kernel<T, DH>), grid, dim3(256), lds, st, d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -426,12 +426,12 @@ template <typename T, int DH> static int launch_bwd(MhaDesc d, int max_q_tiles, 
     size_t lds = dq_lds<T, DH>();
     if (set_lds(mha_bwd_dq_kernel<T, DH>, lds)) return MMAE_ERR_LAUNCH;
     d.max_tiles = max_q_tiles;
-    hipLaunchKernelGGL((mha_bwd_dq_kernel<T, DH>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), lds, st, d);
+    MMAE_LAUNCH((mha_bwd_dq_kernel<T, DH>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), lds, st, d);
     MMAE_CHECK_LAUNCH();
     lds = dkdv_lds<T, DH>();
     if (set_lds(mha_bwd_dkdv_kernel<T, DH>, lds)) return MMAE_ERR_LAUNCH;
     d.max_tiles = max_k_tiles;
-    hipLaunchKernelGGL((mha_bwd_dkdv_kernel<T, DH>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), lds, st, d);
+    MMAE_LAUNCH((mha_bwd_dkdv_kernel<T, DH>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), lds, st, d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

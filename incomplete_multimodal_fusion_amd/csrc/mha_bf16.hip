@@ -624,14 +624,14 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant == 0) {                  // default: 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
-        hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
+        MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
     } else if (head_dim == 64 && g_variant == 8) {           // 8 waves x 16 queries (measured: no gain over 4 x 16)
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
-        hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
+        MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
     } else {                                                 // variant 1 (dh 64) / dh 32: 4 waves x 16 queries
         dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
-        if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_fwd_kernel<64, 4>), grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((mha_bf16_fwd_kernel<32, 4>), grid, dim3(256), 0, st, d);
+        if (head_dim == 64) MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4>), grid, dim3(256), 0, st, d);
+        else MMAE_LAUNCH((mha_bf16_fwd_kernel<32, 4>), grid, dim3(256), 0, st, d);
     }
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -642,13 +642,13 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
     d.max_tiles = max_q_tiles;
     if (head_dim == 64 && g_variant == 2) {                  // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
         d.max_tiles = (max_q_tiles + 1) / 2 + d.nseg;
-        hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);
-    } else if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<64>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((mha_bf16_bwd_dq_kernel<32>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
+        MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);
+    } else if (head_dim == 64) MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
+    else MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<32>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     d.max_tiles = max_k_tiles;
-    if (head_dim == 64) hipLaunchKernelGGL((mha_bf16_bwd_dkdv_kernel<64>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((mha_bf16_bwd_dkdv_kernel<32>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
+    if (head_dim == 64) MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<64>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
+    else MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<32>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

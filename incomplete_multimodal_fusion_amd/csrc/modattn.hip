@@ -244,11 +244,11 @@ extern "C" int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(p.rows, 4)), blk(256);
     if (dtype == MMAE_BF16) {
-        if (head_dim == 64) hipLaunchKernelGGL((modattn_fwd_kernel<bf16, 64>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((modattn_fwd_kernel<bf16, 32>), grid, blk, 0, st, p);
+        if (head_dim == 64) MMAE_LAUNCH((modattn_fwd_kernel<bf16, 64>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((modattn_fwd_kernel<bf16, 32>), grid, blk, 0, st, p);
     } else {
-        if (head_dim == 64) hipLaunchKernelGGL((modattn_fwd_kernel<float, 64>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((modattn_fwd_kernel<float, 32>), grid, blk, 0, st, p);
+        if (head_dim == 64) MMAE_LAUNCH((modattn_fwd_kernel<float, 64>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((modattn_fwd_kernel<float, 32>), grid, blk, 0, st, p);
     }
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -274,7 +274,7 @@ extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, i
     dim3 grid(P, p.nsplit), blk(256);
     const size_t lds = (size_t)4 * 2 * inner * sizeof(float);
     const bool two = inner > 512;
-#define GO(T, DHV, NCHV) hipLaunchKernelGGL((modattn_bwd_kernel<T, DHV, NCHV>), grid, blk, lds, st, p)
+#define GO(T, DHV, NCHV) MMAE_LAUNCH((modattn_bwd_kernel<T, DHV, NCHV>), grid, blk, lds, st, p)
     if (dtype == MMAE_BF16) {
         if (head_dim == 64) { if (two) GO(bf16, 64, 2); else GO(bf16, 64, 1); } else { if (two) GO(bf16, 32, 2); else GO(bf16, 32, 1); }
     } else {
@@ -283,8 +283,8 @@ extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, i
 #undef GO
     MMAE_CHECK_LAUNCH();
     const long n = (long)P * 2 * inner;
-    if (dtype == MMAE_BF16) hipLaunchKernelGGL((modattn_bwd_finish_kernel<bf16>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((modattn_bwd_finish_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
+    if (dtype == MMAE_BF16) MMAE_LAUNCH((modattn_bwd_finish_kernel<bf16>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
+    else MMAE_LAUNCH((modattn_bwd_finish_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, st, p);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

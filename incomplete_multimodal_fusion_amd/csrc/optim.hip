@@ -151,7 +151,7 @@ static int adamw_launch(long n, float* p, const float* g, float* m, float* v, vo
                         void* stream) {
     if (n < 0 || (n % 4) || !p || !g || !m || !v || step < 1) return MMAE_ERR_ARG;
     if (n == 0) return MMAE_OK;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
+    MMAE_LAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
                        reinterpret_cast<bf16*>(shadow_bf16), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ctl);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -166,7 +166,7 @@ extern "C" int mmae_adamw_step(long n, float* p, const float* g, float* m, float
 extern "C" int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, float* ctl4,
                                   void* stream) {
     if (!grad_norm || !ctl4 || max_norm < 0.f || skip_norm < 0.f) return MMAE_ERR_ARG;
-    hipLaunchKernelGGL(adamw_control_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), grad_norm, max_norm,
+    MMAE_LAUNCH(adamw_control_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), grad_norm, max_norm,
                        skip_norm, grad_scale, ctl4);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -182,7 +182,7 @@ extern "C" int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, f
 extern "C" int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream) {
     if (n < 0 || (n % 4) || !p || !shadow_bf16) return MMAE_ERR_ARG;
     if (n == 0) return MMAE_OK;
-    hipLaunchKernelGGL(shadow_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
+    MMAE_LAUNCH(shadow_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
                        reinterpret_cast<bf16*>(shadow_bf16), n);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -191,7 +191,7 @@ extern "C" int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void*
 extern "C" int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16, const void* tiles, int n_tiles, void* stream) {
     if (n_tiles < 0 || !src_bf16 || !dst_bf16 || (n_tiles && !tiles)) return MMAE_ERR_ARG;
     if (n_tiles == 0) return MMAE_OK;
-    hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    MMAE_LAUNCH(transpose_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(src_bf16), reinterpret_cast<bf16*>(dst_bf16),
                        reinterpret_cast<const TrTile*>(tiles));
     MMAE_CHECK_LAUNCH();
@@ -201,7 +201,7 @@ extern "C" int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16,
 extern "C" int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* stream) {
     if (S < 1 || n < 0 || (n % 8) || !partials_bf16 || !out) return MMAE_ERR_ARG;
     if (n == 0) return MMAE_OK;
-    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
+    MMAE_LAUNCH(splitk_sum_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(partials_bf16), S, n, out);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -211,9 +211,9 @@ extern "C" int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, fl
     if (n < 0 || (n % 4) || !g || !partial_ws_2048 || !out_norm) return MMAE_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = grid_for(n);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, partial_ws_2048);
+    MMAE_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, partial_ws_2048);
     MMAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws_2048, nb, out_norm);
+    MMAE_LAUNCH(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws_2048, nb, out_norm);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -251,10 +251,10 @@ static int add_ln_fwd_nc(const AddLnFwd& p, hipStream_t st) {
     const int nc = cdiv(p.D, 256);
     dim3 grid(cdiv(p.rows, 4)), blk(256);
     switch (nc) {
-        case 1: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 1, DOUBLE>), grid, blk, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 2, DOUBLE>), grid, blk, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 3, DOUBLE>), grid, blk, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((add_ln_fwd_kernel<TD, TY, 4, DOUBLE>), grid, blk, 0, st, p); break;
+        case 1: MMAE_LAUNCH((add_ln_fwd_kernel<TD, TY, 1, DOUBLE>), grid, blk, 0, st, p); break;
+        case 2: MMAE_LAUNCH((add_ln_fwd_kernel<TD, TY, 2, DOUBLE>), grid, blk, 0, st, p); break;
+        case 3: MMAE_LAUNCH((add_ln_fwd_kernel<TD, TY, 3, DOUBLE>), grid, blk, 0, st, p); break;
+        case 4: MMAE_LAUNCH((add_ln_fwd_kernel<TD, TY, 4, DOUBLE>), grid, blk, 0, st, p); break;
         default: return MMAE_ERR_ARG;
     }
     MMAE_CHECK_LAUNCH();
@@ -266,8 +266,8 @@ static int add_ln_bwd_nc(const AddLnBwd& p, int nblk, bool hasb, hipStream_t st)
     dim3 grid(nblk), blk(256);
     const size_t lds = (size_t)7 * p.D * sizeof(float);
 #define GO(NCV)                                                                                           \
-    if (hasb) hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, true>), grid, blk, lds, st, p);  \
-    else hipLaunchKernelGGL((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, false>), grid, blk, lds, st, p);
+    if (hasb) MMAE_LAUNCH((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, true>), grid, blk, lds, st, p);  \
+    else MMAE_LAUNCH((add_ln_bwd_kernel<TD, TY, NCV, DOUBLE, false>), grid, blk, lds, st, p);
     switch (nc) {
         case 1: GO(1) break;
         case 2: GO(2) break;
@@ -320,7 +320,7 @@ extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, c
     const bool hasb = beta1 != nullptr || dbeta1 != nullptr || dbeta2 != nullptr;
     int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, hasb, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
+    MMAE_LAUNCH(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
                        dgamma1, dbeta1, dgamma2, dbeta2, accumulate);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -439,7 +439,7 @@ extern "C" int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* 
     const int V = dtype == MMAE_BF16 ? 8 : 4;
     const bool vec = (F % V) == 0 && al16(h) && al16(out);
     const long n = rows * (vec ? F / V : F);
-#define GO(T, V) hipLaunchKernelGGL((geglu_fwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (T*)out, rows, F)
+#define GO(T, V) MMAE_LAUNCH((geglu_fwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (T*)out, rows, F)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -452,7 +452,7 @@ extern "C" int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const 
     const int V = dtype == MMAE_BF16 ? 8 : 4;
     const bool vec = (F % V) == 0 && al16(h) && al16(gout) && al16(dh);
     const long n = rows * (vec ? F / V : F);
-#define GO(T, V) hipLaunchKernelGGL((geglu_bwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (const T*)gout, (T*)dh, rows, F)
+#define GO(T, V) MMAE_LAUNCH((geglu_bwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (const T*)gout, (T*)dh, rows, F)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -463,7 +463,7 @@ extern "C" int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* st
     if (n == 0) return MMAE_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = (n % (dtype == MMAE_BF16 ? 8 : 4)) == 0 && al16(x) && al16(y);
-#define GO(T, V) hipLaunchKernelGGL((gelu_fwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (T*)y, n)
+#define GO(T, V) MMAE_LAUNCH((gelu_fwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (T*)y, n)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -474,7 +474,7 @@ extern "C" int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, vo
     if (n == 0) return MMAE_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = (n % (dtype == MMAE_BF16 ? 8 : 4)) == 0 && al16(x) && al16(g) && al16(dx);
-#define GO(T, V) hipLaunchKernelGGL((gelu_bwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (const T*)g, (T*)dx, n)
+#define GO(T, V) MMAE_LAUNCH((gelu_bwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (const T*)g, (T*)dx, n)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -520,8 +520,8 @@ extern "C" int mmae_gather_rows(int dtype, long rows, int W, const void* src, lo
     if (!ok_dtype(dtype) || rows < 0 || W <= 0 || (W % 4) || !src || !idx || !out || (src_stride % 4) || (out_stride % 4)) return MMAE_ERR_ARG;
     if (rows == 0) return MMAE_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MMAE_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)src, idx, (bf16*)out, rows, W, src_stride, out_stride);
-    else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)src, idx, (float*)out, rows, W, src_stride, out_stride);
+    if (dtype == MMAE_BF16) MMAE_LAUNCH((gather_rows_kernel<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)src, idx, (bf16*)out, rows, W, src_stride, out_stride);
+    else MMAE_LAUNCH((gather_rows_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)src, idx, (float*)out, rows, W, src_stride, out_stride);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
@@ -532,11 +532,11 @@ extern "C" int mmae_scatter_rows(int dtype, long rows, int W, const void* src, l
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(rows, 4)), blk(256);
     if (dtype == MMAE_BF16) {
-        if (accumulate) hipLaunchKernelGGL((scatter_rows_kernel<bf16, true>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
-        else hipLaunchKernelGGL((scatter_rows_kernel<bf16, false>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        if (accumulate) MMAE_LAUNCH((scatter_rows_kernel<bf16, true>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        else MMAE_LAUNCH((scatter_rows_kernel<bf16, false>), grid, blk, 0, st, (const bf16*)src, idx, (bf16*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
     } else {
-        if (accumulate) hipLaunchKernelGGL((scatter_rows_kernel<float, true>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
-        else hipLaunchKernelGGL((scatter_rows_kernel<float, false>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        if (accumulate) MMAE_LAUNCH((scatter_rows_kernel<float, true>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
+        else MMAE_LAUNCH((scatter_rows_kernel<float, false>), grid, blk, 0, st, (const float*)src, idx, (float*)dst, rows, W, src_stride, dst_stride, filter, filter_value);
     }
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
@@ -595,10 +595,10 @@ extern "C" int mmae_colsum(int dtype, long rows, int cols, const void* x, long l
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = colsum_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
-    if (dtype == MMAE_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, rows, cols, ld, rpb, ws);
-    else hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, rows, cols, ld, rpb, ws);
+    if (dtype == MMAE_BF16) MMAE_LAUNCH((colsum_partial_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, rows, cols, ld, rpb, ws);
+    else MMAE_LAUNCH((colsum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, rows, cols, ld, rpb, ws);
     MMAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, ws, nb, cols, out);
+    MMAE_LAUNCH(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, ws, nb, cols, out);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -113,14 +113,14 @@ extern "C" int mmae_stage_tiles(int kind, int in_dtype, int B, int C, int H, int
     long nb = (n + 255) / 256; if (nb > 8192) nb = 8192;
     const bool u8 = in_dtype == MMAE_RAW_U8;
     if (kind == MMAE_STAGE_ZSCORE) {
-        if (u8) hipLaunchKernelGGL(stage_zscore_kernel<unsigned char>, dim3(B * C), dim3(1024), 0, st, d);
-        else hipLaunchKernelGGL(stage_zscore_kernel<float>, dim3(B * C), dim3(1024), 0, st, d);
+        if (u8) MMAE_LAUNCH(stage_zscore_kernel<unsigned char>, dim3(B * C), dim3(1024), 0, st, d);
+        else MMAE_LAUNCH(stage_zscore_kernel<float>, dim3(B * C), dim3(1024), 0, st, d);
     } else if (kind == MMAE_STAGE_SAR_DB) {
-        if (u8) hipLaunchKernelGGL((stage_affine_kernel<unsigned char, MMAE_STAGE_SAR_DB>), dim3((unsigned)nb), dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((stage_affine_kernel<float, MMAE_STAGE_SAR_DB>), dim3((unsigned)nb), dim3(256), 0, st, d);
+        if (u8) MMAE_LAUNCH((stage_affine_kernel<unsigned char, MMAE_STAGE_SAR_DB>), dim3((unsigned)nb), dim3(256), 0, st, d);
+        else MMAE_LAUNCH((stage_affine_kernel<float, MMAE_STAGE_SAR_DB>), dim3((unsigned)nb), dim3(256), 0, st, d);
     } else {
-        if (u8) hipLaunchKernelGGL((stage_affine_kernel<unsigned char, MMAE_STAGE_AFFINE>), dim3((unsigned)nb), dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((stage_affine_kernel<float, MMAE_STAGE_AFFINE>), dim3((unsigned)nb), dim3(256), 0, st, d);
+        if (u8) MMAE_LAUNCH((stage_affine_kernel<unsigned char, MMAE_STAGE_AFFINE>), dim3((unsigned)nb), dim3(256), 0, st, d);
+        else MMAE_LAUNCH((stage_affine_kernel<float, MMAE_STAGE_AFFINE>), dim3((unsigned)nb), dim3(256), 0, st, d);
     }
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;

@@ -8,7 +8,7 @@ import torch
 
 from incomplete_multimodal_fusion_amd import _lib
 
-QUERIES = {"mmae_abi_version", "mmae_modattn_bwd_nsplit",
+QUERIES = {"mmae_abi_version", "mmae_last_hip_error", "mmae_modattn_bwd_nsplit",
            "mmae_add_ln_bwd_ws_floats", "mmae_hardneg_ws_floats"}          # setters / size queries: no pointers to validate
 
 
