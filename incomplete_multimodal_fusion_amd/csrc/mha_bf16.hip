@@ -11,6 +11,7 @@
 //   * softmax in the exp2 domain with one fma per score, and the key-bound mask only on a segment's ragged last tile.
 // Tried and rejected (tools/bench_attn.py, one process): prefetch distance 2 (-4 %), 128-row query tiles / 8 waves (+-0),
 // one persistent block per (sample, head) pair (-17 %: many short blocks overlap better than few long ones).
+#include <type_traits>
 #include "mha_common.hpp"
 #include "mmae_hip.h"
 
@@ -618,11 +619,284 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------ forward, 32x32x16
+// Second-generation forward for head_dim 64 (variants 3 / 4 of mmae_internal.h; see DESIGN.md for the A/B numbers).
+// What changes against mha_bf16_fwd_kernel:
+//   * v_mfma_f32_32x32x16_bf16 with the score tile computed transposed (S^T = K Q^T): a lane owns ONE query and 16 keys of
+//     each 32-key block, so the row maximum is an in-lane max3 chain plus one v_permlane32_swap, and the exponentiated
+//     accumulator registers 8s..8s+7 ARE the B operand of O^T += V^T P^T for k-step s (k-slot permutation absorbed by the
+//     transposed V read) -- half the MFMA instructions per FLOP, 24 instead of 8 free VALU issue cycles under each MFMA;
+//   * the running maximum enters as the INITIAL accumulator (-m), Q is pre-scaled by scale*log2(e): a score costs one
+//     v_exp_f32 and one add -- no fma, no subtract; the O / l rescale happens only when a row's new scores exceed the
+//     running reference by 2^6 (wave-uniform branch; exact algebra, only the bf16 rounding point of P moves);
+//   * double-buffered K / V images (one barrier per key tile); the next tile's registers are written to the idle buffer
+//     between the softmax and the PV products, so the ds_write latency hides under the PV MFMAs;
+//   * K image pitch 144 B (b128 row reads conflict-free), V image pitch 192 B (the 4 x 16-column blocks of one transposed
+//     read land on the four 64-byte quarters of the 256-byte bank row: conflict-free).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float swap32_max(float v) {
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float swap32_sum(float v) {
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+// A operand of O^T[dh, query] += V^T[dh, key] P^T[key, query] for the 16 keys base..base+15 and dh block dhb (32 rows):
+// element j of lane (r = lane & 31, hh = lane >> 5) is V[base + 8*(j >> 2) + 4*hh + (j & 3)][32*dhb + r] -- the k-slot order in
+// which the 32x32 score accumulator hands out its registers (cdna_hip_programming.md, "An accumulator tile as the next
+// MFMA's operand").  Two transposed reads of 4 keys x 16 columns per 16-lane group.
+__device__ __forceinline__ bf16x8 tr32_frag(const bf16* img, int pitch, int base, int dhb, int lane) {
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* a0 = img + (base + 4 * (g16 >> 1) + q) * pitch + 32 * dhb + 16 * (g16 & 1) + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(a0 + 8 * pitch));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+// staging of one [<= 64 rows][64] bf16 tile by 256 threads: 2 chunks of 16 B per thread, LDS pitch PITCH elements
+template <int PITCH> struct Stage64 {
+    int boff[2], loff[2], row_bytes;
+    __device__ __forceinline__ void init(int tid, long stride, int col0) {
+        row_bytes = (int)stride * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, rr = c >> 3, dc = c & 7;
+            boff[i] = (rr * (int)stride + col0 + dc * 8) * 2; loff[i] = rr * PITCH + dc * 8;
+        }
+    }
+    __device__ __forceinline__ void load(const bf16* base, int n, bf16x8 (&reg)[2]) const {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, n * row_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) reg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, boff[i], 0, 0));
+    }
+    __device__ __forceinline__ void store(bf16* img, const bf16x8 (&reg)[2]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(img + loff[i]) = reg[i];
+    }
+};
+
+#define FWD32_THR 6.0f    // log2 domain: P <= 2^6 between rescales
+
+template <int QB>
+__global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
+    constexpr int DH = 64, BM = 128 * QB, KP = 72, VP = 96;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * KP];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * VP];
+    __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const BlockSel bs = decode_block(blockIdx.x, p.max_tiles, p.B, p.H);
+    if (bs.b < 0) return;
+    const int b = bs.b, h = bs.h;
+    SegTab st; st.load(p, b, lane);
+    const TileSel ts = pick_tile<BM>([&](int s) { return st.ql(s); }, p.nseg, bs.t);
+    if (ts.seg < 0) return;
+    const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
+    const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
+    int first_row = 0, first_n = 0;                               // tile 0, known to every wave without the shared list
+    if (wave == 0) {
+        int n = 0;
+        for (int s = kp.begin; s < kp.end; ++s) {
+            const int L = st.kl(s), r0 = st.ks(s);
+            for (int j0 = 0; j0 < L && n < MAXT; j0 += 64) { if (lane == 0) { tl_row[n] = r0 + j0; tl_n[n] = min(64, L - j0); } ++n; }
+        }
+        if (lane == 0) tl_cnt = n;
+    }
+    for (int s = kp.end - 1; s >= kp.begin; --s) {
+        const int L = st.kl(s);
+        if (L > 0) { first_row = st.ks(s); first_n = min(64, L); }
+    }
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    Stage64<KP> ixk; Stage64<VP> ixv;
+    ixk.init(tid, p.k_stride, h * DH);
+    ixv.init(tid, p.v_stride, h * DH);
+    bf16x8 kreg[2], vreg[2];
+    first_row = uni(first_row); first_n = uni(first_n);
+    if (first_n > 0) {
+        ixk.load(kg + (long)first_row * p.k_stride, first_n, kreg);
+        ixv.load(vg + (long)first_row * p.v_stride, first_n, vreg);
+    }
+    // Q^T fragments (B operand of S^T = K Q^T), pre-scaled into the exp2 domain
+    int myq[QB]; bool qvalid[QB];
+    bf16x8 qf[QB][4];
+    {
+        const float c = p.scale * LOG2E;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            myq[qb] = (wave * QB + qb) * 32 + r;
+            qvalid[qb] = myq[qb] < ts.n;
+            const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq[qb]) * p.q_stride + h * DH + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // fully masked rows (empty key segment, finite masked_fill in the reference) attend every key uniformly:
+                // a zero query gives every swept key the score 0 -- same loop, no special case
+                qf[qb][ks] = (qvalid[qb] && !kp.uniform) ? ld8(qp + 16 * ks) : z8();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+            }
+        }
+    }
+    float mref[QB], lsum[QB];
+    f32x16 oacc[QB][2], negm[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mref[qb] = 0.f; lsum[qb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[qb][i] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
+    }
+    __syncthreads();                                               // tile list visible
+    const int ntile = uni(tl_cnt);
+    if (ntile > 0) {
+        ixk.store(Ks[0], kreg);
+        ixv.store(Vs[0], vreg);
+        if (ntile > 1) {
+            const long r1 = uni(tl_row[1]); const int n1 = uni(tl_n[1]);
+            ixk.load(kg + r1 * p.k_stride, n1, kreg);
+            ixv.load(vg + r1 * p.v_stride, n1, vreg);
+        }
+    }
+    __syncthreads();
+    const bf16* kbase = Ks[0] + r * KP + 8 * hh;
+    // Padded keys of a segment's ragged last tile (kn < 64; their K and V rows read as zeros) leave the softmax through the
+    // matrix core as well: one extra k-step whose Q side is the constant e_0 and whose K side holds -1e30 in slot 0 of every
+    // padded key adds -1e30 to exactly those scores.  Two MFMAs behind a scalar branch instead of 64 compare/select pairs
+    // (which hipcc if-converts into every iteration when they stand alone under the branch).
+    bf16x8 qone = z8();
+    if (hh == 0) qone[0] = (bf16)1.0f;
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const int kn = uni(tl_n[t]);
+        const bf16* Kc = kbase + cur * (64 * KP);
+        const bf16* Vc = Vs[cur];
+        // ---- S'^T = K Q~^T - m : the running reference enters as the C operand of the first k-step (negm: a register splat)
+        f32x16 sacc[QB][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kfr = ld8(Kc + 32 * kb * KP + 16 * ks);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mma32(kfr, qf[qb][ks], ks == 0 ? negm[qb] : sacc[qb][kb]);
+            }
+        if (kn < 64) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 kmask = z8();
+                if (hh == 0 && 32 * kb + r >= kn) kmask[0] = (bf16)(-1.0e30f);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mma32(kmask, qone, sacc[qb][kb]);
+            }
+        }
+        // ---- softmax in registers
+        bf16x8 pb[QB][2][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = fmaxf(sacc[qb][0][0], sacc[qb][1][0]);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, sacc[qb][0][i]), sacc[qb][1][i]);
+            mx = swap32_max(mx);
+            const bool need = (t == 0) | (mx > FWD32_THR);
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {          // wave-uniform: first tile, or some row outgrew the reference
+                const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+                if (t > 0) {
+                    const float alpha = fast_exp2(-delta);
+                    lsum[qb] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) oacc[qb][d][i] *= alpha;
+                }
+                mref[qb] += delta;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) negm[qb][i] = -mref[qb];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[qb][kb][i] -= delta;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float e = fast_exp2(sacc[qb][kb][i]); sacc[qb][kb][i] = e; rs += e; }
+            lsum[qb] += rs;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[qb][kb][s2][j] = (bf16)sacc[qb][kb][8 * s2 + j];
+                }
+        }
+        // ---- the next tile's registers go to the idle buffer; the write latency hides under the PV products
+        if (t + 1 < ntile) {
+            ixk.store(Ks[cur ^ 1], kreg);
+            ixv.store(Vs[cur ^ 1], vreg);
+        }
+        // ---- O^T += V^T P^T : 2 key blocks x 2 k-steps x 2 dh blocks
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const bf16x8 vfr = tr32_frag(Vc, VP, 32 * kb + 16 * s2, d, lane);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = mma32(vfr, pb[qb][kb][s2], oacc[qb][d]);
+                }
+        __syncthreads();
+        if (t + 2 < ntile) {
+            const long r2 = uni(tl_row[t + 2]); const int n2 = uni(tl_n[t + 2]);
+            ixk.load(kg + r2 * p.k_stride, n2, kreg);
+            ixv.load(vg + r2 * p.v_stride, n2, vreg);
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lq = swap32_sum(lsum[qb]);
+        if (qvalid[qb]) {
+            const float inv = lq > 0.f ? 1.f / lq : 0.f;
+            bf16* op = reinterpret_cast<bf16*>(p.o) + (qrow0 + myq[qb]) * p.o_stride + h * DH + 4 * hh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v;
+                    v[0] = oacc[qb][d][4 * i] * inv; v[1] = oacc[qb][d][4 * i + 1] * inv;
+                    v[2] = oacc[qb][d][4 * i + 2] * inv; v[3] = oacc[qb][d][4 * i + 3] * inv;
+                    st4(op + 32 * d + 8 * i, v);
+                }
+            if (hh == 0) p.lse[(long)h * p.stat_stride + qrow0 + myq[qb]] = lq > 0.f ? mref[qb] * LN2 + __logf(lq) : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ host side
 // `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
-    if (head_dim == 64 && g_variant == 0) {                  // default: 4 waves x 32 queries = 128-query tiles
+    if (head_dim == 64 && (g_variant == 3 || g_variant == 4)) {   // 32x32x16 forward: 128- (QB 1) / 256-query (QB 2) tiles
+        MhaDesc e = d;
+        if (g_variant == 3) {
+            e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
+            MMAE_LAUNCH((mha_bf16_fwd32_kernel<1>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
+        } else {
+            e.max_tiles = (d.max_tiles + 3) / 4 + d.nseg;
+            MMAE_LAUNCH((mha_bf16_fwd32_kernel<2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
+        }
+    } else if (head_dim == 64 && g_variant == 0) {           // default: 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
     } else if (head_dim == 64 && g_variant == 8) {           // 8 waves x 16 queries (measured: no gain over 4 x 16)

@@ -551,54 +551,85 @@ template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long rows, int cols, long ld,
                                                              int rows_per_block, float* __restrict__ ws) {
     constexpr int V = 16 / sizeof(T);
-    const int cg = cols / V;                                  // column groups (cols % V == 0)
+    __shared__ float red[256 * V];
+    const int cg = cols / V;                                  // column groups of 16 bytes (cols % V == 0)
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    for (int g0 = threadIdx.x; g0 < cg; g0 += 256) {
+    auto load_add = [&](long r, int g, float (&acc)[V]) {
+        if (sizeof(T) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(x) + r * ld + (long)g * V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += (float)v[j];
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ld + (long)g * V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j];
+        }
+    };
+    if (cg <= 256) {
+        // 256 / cg rows in flight per iteration: thread (rr, g) walks rows rr, rr + rpi, ... of the strip in column group g
+        const int rpi = 256 / cg, g = threadIdx.x % cg, rr = threadIdx.x / cg;
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
-        for (long r = r0; r < r1; ++r) {
-            if (sizeof(T) == 2) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(x) + r * ld + (long)g0 * V);
+        if (rr < rpi)
+            for (long r = r0 + rr; r < r1; r += rpi) load_add(r, g, acc);
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] += (float)v[j];
-            } else {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ld + (long)g0 * V);
+        for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = acc[j];
+        __syncthreads();
+        if (threadIdx.x < cg) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] += v[j];
+            for (int j = 0; j < V; ++j) {
+                float sum = 0.f;
+                for (int k = 0; k < rpi; ++k) sum += red[(k * cg + threadIdx.x) * V + j];       // fixed order: deterministic
+                ws[(long)blockIdx.x * cols + (long)threadIdx.x * V + j] = sum;
             }
         }
+    } else {
+        for (int g = threadIdx.x; g < cg; g += 256) {
+            float acc[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) ws[(long)blockIdx.x * cols + (long)g0 * V + j] = acc[j];
+            for (int j = 0; j < V; ++j) acc[j] = 0.f;
+            for (long r = r0; r < r1; ++r) load_add(r, g, acc);
+#pragma unroll
+            for (int j = 0; j < V; ++j) ws[(long)blockIdx.x * cols + (long)g * V + j] = acc[j];
+        }
     }
 }
+// out[c] = sum_b ws[b][c]: 4 partial-row groups x 64 columns per block, combined in fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int nblk, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += ws[(long)b * cols + c]; s1 += ws[(long)(b + 1) * cols + c];
-        s2 += ws[(long)(b + 2) * cols + c]; s3 += ws[(long)(b + 3) * cols + c];
-    }
-    for (; b < nblk; ++b) s0 += ws[(long)b * cols + c];
-    out[c] = (s0 + s1) + (s2 + s3);
+    __shared__ float red[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int b = rg; b < nblk; b += 4) s += ws[(long)b * cols + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) out[c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
-static int colsum_blocks(long rows) { long b = (rows + 63) / 64; if (b > 1024) b = 1024; if (b < 1) b = 1; return (int)b; }
-extern "C" long mmae_colsum_ws_floats(long rows, int cols) { return rows < 0 || cols <= 0 ? MMAE_ERR_ARG : (long)colsum_blocks(rows) * cols; }
+static int colsum_rows_per_block(long rows, int cols, int V) {
+    const int cg = cols / V, rpi = cg <= 256 ? 256 / cg : 1;
+    long rpb = (rows + 255) / 256;                                     // at most 256 partial rows
+    if (rpb < 16L * rpi) rpb = 16L * rpi;                              // and at least 16 loads per thread
+    return (int)rpb;
+}
+static int colsum_blocks(long rows, int cols, int V) {
+    const int rpb = colsum_rows_per_block(rows, cols, V);
+    long b = (rows + rpb - 1) / rpb;
+    return (int)(b < 1 ? 1 : b);
+}
+extern "C" long mmae_colsum_ws_floats(long rows, int cols) { return rows < 0 || cols <= 0 ? MMAE_ERR_ARG : 256L * cols; }
 extern "C" int mmae_colsum(int dtype, long rows, int cols, const void* x, long ld, float* out, float* ws, void* stream) {
     if (!ok_dtype(dtype) || rows < 0 || cols <= 0 || !x || !out || !ws) return MMAE_ERR_ARG;
     const int V = dtype == MMAE_BF16 ? 8 : 4;
     if ((cols % V) || (ld % V) || ld < cols || (reinterpret_cast<uintptr_t>(x) & 15)) return MMAE_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nb = colsum_blocks(rows);
-    const int rpb = (int)((rows + nb - 1) / nb);
+    const int nb = colsum_blocks(rows, cols, V), rpb = colsum_rows_per_block(rows, cols, V);
     if (dtype == MMAE_BF16) MMAE_LAUNCH((colsum_partial_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, rows, cols, ld, rpb, ws);
     else MMAE_LAUNCH((colsum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, rows, cols, ld, rpb, ws);
     MMAE_CHECK_LAUNCH();
-    MMAE_LAUNCH(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, ws, nb, cols, out);
+    MMAE_LAUNCH(colsum_finish_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, ws, nb, cols, out);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -370,9 +370,9 @@ def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, or
 
 
 def mha_cross(q: torch.Tensor, kv: torch.Tensor, H: int, dh: int, qseg: Segments, kseg: Segments, scale: float,
-              empty_mode: int = 0) -> torch.Tensor:
+              empty_mode: int = 0, variant: int = 0) -> torch.Tensor:
     """q (rows_q, H*dh), kv (rows_k, 2*H*dh) = [k | v]."""
-    return _MHA.apply(q, kv, 0, 0, H * dh, H, dh, qseg, kseg, scale, empty_mode)
+    return _MHA.apply(q, kv, 0, 0, H * dh, H, dh, qseg, kseg, scale, empty_mode, variant)
 
 
 # ------------------------------------------------------------------------------------------------ modality attention

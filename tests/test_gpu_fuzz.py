@@ -12,13 +12,14 @@ from tests.test_gpu_kernels import DEV, close, dense_attention_ref
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-def test_fuzz_attention_segments(T):
+@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 3), (torch.bfloat16, 4)])
+def test_fuzz_attention_segments(T, variant):
     from incomplete_multimodal_fusion_amd import ops
     rng = random.Random(1234)
     torch.manual_seed(77)
     for case in range(24):
-        dh = rng.choice([32, 64]); H = rng.choice([1, 2, 3, 8]); nseg = rng.randint(1, 5); B = rng.randint(1, 4)
+        dh = rng.choice([32, 64]) if variant == 0 else 64
+        H = rng.choice([1, 2, 3, 8]); nseg = rng.randint(1, 5); B = rng.randint(1, 4)
         empty_mode = rng.choice([0, 1]); same = rng.random() < 0.5
         pick = lambda: rng.choice([0, 0, 1, 7, 63, 64, 65, 100, 128, 129, 191, 200, 257])
         qlens = torch.tensor([[pick() for _ in range(nseg)] for _ in range(B)], dtype=torch.int32)
@@ -43,7 +44,7 @@ def test_fuzz_attention_segments(T):
         qseg = ops.Segments(qst.to(DEV), qlens.to(DEV), max(int(qlens.sum(1).max()), 1), covers_all=gap == 0 and nq == int(qlens.sum()))
         kseg = ops.Segments(kst.to(DEV), klens.to(DEV), max(int(klens.sum(1).max()), 1), covers_all=gap == 0 and nk == int(klens.sum()))
         scale = dh ** -0.5
-        out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode)
+        out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant)
         out.backward(g.to(DEV, T))
         q64 = qd.detach().cpu().double().reshape(nq, H, dh).requires_grad_()
         kv64 = kvd.detach().cpu().double()

@@ -273,9 +273,11 @@ def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
     return out
 
 
-@pytest.mark.parametrize("T,dh", [(torch.float32, 64), (torch.float32, 32), (torch.bfloat16, 64), (torch.bfloat16, 32)])
+# variant: kernel variant of csrc/mmae_internal.h (0 = what the product ABI runs; 3 / 4 = 32x32x16 forward, 128 / 256 queries)
+@pytest.mark.parametrize("T,dh,variant", [(torch.float32, 64, 0), (torch.float32, 32, 0), (torch.bfloat16, 64, 0),
+                                          (torch.bfloat16, 32, 0), (torch.bfloat16, 64, 3), (torch.bfloat16, 64, 4)])
 @pytest.mark.parametrize("empty_mode", [0, 1])
-def test_mha_kernel_ragged_segments(T, dh, empty_mode):
+def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     from incomplete_multimodal_fusion_amd import ops
     torch.manual_seed(3)
     H, nseg = 3, 4
@@ -298,7 +300,7 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode):
     qseg = ops.Segments(qst.to(DEV), qlens.to(DEV), int(qlens.sum(1).max()))
     kseg = ops.Segments(kst.to(DEV), klens.to(DEV), int(klens.sum(1).max()))
     scale = dh ** -0.5
-    out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode)
+    out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant)
     out.backward(g.to(DEV, T))
     # reference on what the kernel actually saw (bf16-rounded inputs), fp64
     q64 = qd.detach().cpu().double().reshape(nq, H, dh).requires_grad_()
@@ -313,18 +315,24 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode):
     close(kvd.grad[:, I:], v64.grad.reshape(nk, I), tol * 2, "dv")
 
 
-@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-def test_mha_online_softmax_rescale_branch(T):
-    """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path)."""
+@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 3), (torch.bfloat16, 4)])
+@pytest.mark.parametrize("shift", [0.0, -40.0])
+def test_mha_online_softmax_rescale_branch(T, variant, shift):
+    """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path; the 32x32x16 forward
+    defers the rescale until a row outgrows its reference by 2^6, so spikes below AND above that threshold are used).
+    shift: every score of query 10 moved far below zero (a constant along the key axis: softmax unchanged) -- the running
+    reference must follow the data, not sit at 0."""
     from incomplete_multimodal_fusion_amd import ops
     torch.manual_seed(5)
     H, dh, n = 1, 64, 300
     q = torch.randn(n, dh); k = torch.randn(n, dh) * 0.1; v = torch.randn(n, dh)
-    for j, amp in ((70, 4.0), (140, 9.0), (299, 20.0)):
+    for j, amp in ((30, 1.5), (70, 4.0), (140, 9.0), (299, 20.0)):
         k[j] = q[10] * amp / q[10].norm()
+    if shift:
+        k = k + shift * dh ** 0.5 * q[10][None] / (q[10] @ q[10])       # adds `shift` to every scaled score of query 10
     qkv = torch.cat([q, k, v], dim=1).to(DEV, T).requires_grad_()
     seg = ops.Segments.dense(1, n, DEV)
-    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5)
+    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variant)
     out.sum().backward()
     x = qkv.detach().cpu().double().requires_grad_()
     qq, kk, vv = x[:, :dh], x[:, dh:2 * dh], x[:, 2 * dh:]
@@ -421,12 +429,14 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     qkv = torch.randn(r, 3 * I, device=DEV).to(torch.bfloat16)
     g = torch.randn(r, I, device=DEV).to(torch.bfloat16)
     res = []
-    for variant in (-1, 0):                    # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path
+    # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path, 3 / 4: 32x32x16 forward (dh 64 only)
+    for variant in ((-1, 0, 3, 4) if dh == 64 else (-1, 0)):
         x = qkv.clone().requires_grad_()
         out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)
         res.append((out.float(), x.grad.float()))
-    close(res[1][0], res[0][0], 1e-2, "out"); close(res[1][1], res[0][1], 2e-2, "grads")
+    for i in range(1, len(res)):
+        close(res[i][0], res[0][0], 1e-2, "out"); close(res[i][1], res[0][1], 2e-2, "grads")
 
 
 def test_colsum_bias_gradient_kernel():

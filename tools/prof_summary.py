@@ -4,6 +4,7 @@
   python tools/prof_summary.py stats  <kernel_stats.csv> <steps> > profiles/rNN_kernel_stats.md
   python tools/prof_summary.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_hbm.md
   python tools/prof_summary.py json   <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_hbm.json
+  python tools/prof_summary.py sq     <SQ counter_collection.csv> <steps> [json] > profiles/rNN_sq_step.md | .json
 
 PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide coalesced read, so fetched bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
@@ -64,10 +65,64 @@ def pmc_json(fetch, write):
                                 "WRITE_SIZE*1024", "kernels": d}, indent=1))
 
 
+def sq(path, steps, as_json=False):
+    """Per-kernel and whole-step SQ view of `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
+    SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py ...`.
+    MFMA-busy % of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): BUSY_CYCLES is summed over the chip's
+    256 x 4 SIMDs (it equals 16 x the 16x16x32 / 32 x the 32x32x16 MFMA count, MI355X_MICROARCH.md cycle constants),
+    GRBM_GUI_ACTIVE is the dispatch's length in shader clocks.  Whole step: sum of busy cycles / (1024 x sum of GUI_ACTIVE)
+    over every dispatch of the profiled steps (idle gaps between kernels are not in the denominator)."""
+    import json
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    seen = set()
+    for x in csv.DictReader(open(path)):
+        k = x["Kernel_Name"]
+        acc[k][x["Counter_Name"]] += float(x["Counter_Value"])
+        if (x["Dispatch_Id"], k) not in seen:
+            seen.add((x["Dispatch_Id"], k))
+            calls[k] += 1
+            acc[k]["ns"] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+    SIMDS = 1024.0
+    tot = collections.defaultdict(float)
+    rows = []
+    for k, c in acc.items():
+        for n, v in c.items():
+            tot[n] += v
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        rows.append(dict(kernel=k, calls=calls[k], ms=c["ns"] / 1e6,
+                         mfma_busy_pct=100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * gui) if gui else 0.0,
+                         valu_per_mfma=c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_MFMA"] if c.get("SQ_INSTS_MFMA") else None,
+                         lds_conflict_pct=100.0 * c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
+                         wait_pct=100.0 * c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                         mfma_busy_cycles=c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), gui_active=gui))
+    rows.sort(key=lambda r: -r["mfma_busy_cycles"])
+    step = dict(mfma_busy_pct=round(100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * tot["GRBM_GUI_ACTIVE"]), 2) if tot["GRBM_GUI_ACTIVE"] else None,
+                kernel_ms_per_step=round(tot["ns"] / 1e6 / steps, 2), steps=steps,
+                insts_valu=tot["SQ_INSTS_VALU"], insts_mfma=tot["SQ_INSTS_MFMA"])
+    if as_json:
+        print(json.dumps({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT "
+                                    "SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 2 "
+                                    "--no-cpu-baseline --legs none (B=256); MFMA-busy = BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE)",
+                          "step": step, "kernels": {r["kernel"]: {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"}
+                                                    for r in rows[:40]}}, indent=1))
+        return
+    print("whole step (all dispatches of %d profiled steps): MFMA-busy %.1f %% of the chip's SIMD cycles while a kernel runs; "
+          "%.1f ms of kernels per step; %.3g VALU / %.3g MFMA instructions" % (steps, step["mfma_busy_pct"], step["kernel_ms_per_step"],
+                                                                              tot["SQ_INSTS_VALU"], tot["SQ_INSTS_MFMA"]))
+    print("\n| kernel | calls | total ms | MFMA busy % | VALU / MFMA | LDS cycles conflicted % | wave cycles parked (s_waitcnt / barrier) % |\n|---|---|---|---|---|---|---|")
+    f = lambda v, fmt="%.1f": "-" if v is None else fmt % v
+    for r in rows[:24]:
+        print("| `%s` | %d | %.2f | %.1f | %s | %s | %s |" % (short(r["kernel"]), r["calls"], r["ms"], r["mfma_busy_pct"], f(r["valu_per_mfma"]),
+                                                               f(r["lds_conflict_pct"]), f(r["wait_pct"])))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "json":
         pmc_json(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], int(sys.argv[3]), len(sys.argv) > 4 and sys.argv[4] == "json")
     else:
         pmc(sys.argv[2], sys.argv[3])
