@@ -438,10 +438,10 @@ def main():
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "launches": ln_n},
             # the flagship MFMA kernel of the path (north_star: fusion-attention block), mask-aware algorithmic FLOPs
-            "roofline_attention": {"kernel": "mha_bf16_fwd_kernel<64, 4, 2>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
+            "roofline_attention": {"kernel": "mha_bf16_fwd32_kernel<1, false>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
-                         "traffic": pmc_traffic("mha_bf16_fwd_kernel") if (not args.fp32 and args.batch == 256) else None,
+                         "traffic": pmc_traffic("mha_bf16_fwd") if (not args.fp32 and args.batch == 256) else None,
                          "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
                          "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 512 * 2,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch},

@@ -52,6 +52,10 @@ def lib():
             raise MmaeLibraryError(
                 "libmmae_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C incomplete_multimodal_fusion_amd/csrc`. There is no CPU / eager fallback." % LIB_PATH)
+        # torch ships its own libamdhip64 (torch/lib); it must be in the process BEFORE this library resolves its
+        # libamdhip64.so.7 dependency, or the loader adds /opt/rocm's copy as a SECOND HIP runtime that does not know torch's
+        # allocations (hipMemsetAsync on a torch pointer then fails while plain kernel launches still "work").
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         protos = dict(parse_header())
         protos.update(parse_header(INTERNAL_HEADER_PATH))

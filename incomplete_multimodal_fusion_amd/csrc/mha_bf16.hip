@@ -71,7 +71,13 @@ __device__ __forceinline__ void st4(bf16* p, const f32x4& v) {
 }
 
 template <int DH, int NT = 256> struct Geo {
-    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH + 8, CPR = DH / 8, NCH = 64 * CPR / NT;
+    // LDS row pitch.  DH 64: 160 B.  With 16-byte slots s = (10 * row + chunk) mod 16 the ds_read_b128 lane groups
+    // ({0-3, 12-15, 20-27}: rows 0-3 / 12-15 of chunk g, rows 4-11 of chunk g+1) hit 16 distinct slots, and the 8 rows x 32 B of
+    // one transposed read (ds_read_b64_tr_b16, 32-lane half) start at banks 40 * row mod 64 = {0,40,16,56,32,8,48,24}: both
+    // conflict-free.  The former 144 B pitch (DH + 8) made both kinds of read 2-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    // was 36-41 % in all three kernels, with the LDS array 54-57 % busy in the backward ones (now 0 % / 33-37 %; the kernel
+    // times did not move: the LDS array was not what they wait for, see the forward kernel's notes on block start-up latency).
+    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH == 64 ? 80 : DH + 8, CPR = DH / 8, NCH = 64 * CPR / NT;
 };
 
 // global -> registers: this thread's chunks of a [<=64 rows][DH] tile (rows >= n zero-filled)
@@ -101,10 +107,11 @@ struct SegTab {
         const int i = b * p.nseg + (lane < p.nseg ? lane : 0);
         qlen = p.q_len[i]; qst = p.q_start[i]; klen = p.k_len[i]; kst = p.k_start[i];
     }
-    __device__ __forceinline__ int ql(int s) const { return __shfl(qlen, s); }
-    __device__ __forceinline__ int qs(int s) const { return __shfl(qst, s); }
-    __device__ __forceinline__ int kl(int s) const { return __shfl(klen, s); }
-    __device__ __forceinline__ int ks(int s) const { return __shfl(kst, s); }
+    // v_readlane_b32 (the segment index is wave-uniform): a VALU -> SGPR move, not a ds_bpermute trip through the LDS crossbar
+    __device__ __forceinline__ int ql(int s) const { return __builtin_amdgcn_readlane(qlen, __builtin_amdgcn_readfirstlane(s)); }
+    __device__ __forceinline__ int qs(int s) const { return __builtin_amdgcn_readlane(qst, __builtin_amdgcn_readfirstlane(s)); }
+    __device__ __forceinline__ int kl(int s) const { return __builtin_amdgcn_readlane(klen, __builtin_amdgcn_readfirstlane(s)); }
+    __device__ __forceinline__ int ks(int s) const { return __builtin_amdgcn_readlane(kst, __builtin_amdgcn_readfirstlane(s)); }
 };
 // (segment, 64-row tile) of linear tile index t over the lengths len(s); seg = -1: none
 template <int BM = 64, typename F> __device__ __forceinline__ TileSel pick_tile(F len, int nseg, int t) {
@@ -620,19 +627,34 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dkdv_kernel(MhaDesc p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ forward, 32x32x16
-// Second-generation forward for head_dim 64 (variants 3 / 4 of mmae_internal.h; see DESIGN.md for the A/B numbers).
-// What changes against mha_bf16_fwd_kernel:
+// Second-generation forward for head_dim 64 (what mmae_mha_fwd runs; the 16x16x32 kernel above stays as variant 1 / 8 and
+// serves head_dim 32).  What changes against mha_bf16_fwd_kernel:
 //   * v_mfma_f32_32x32x16_bf16 with the score tile computed transposed (S^T = K Q^T): a lane owns ONE query and 16 keys of
 //     each 32-key block, so the row maximum is an in-lane max3 chain plus one v_permlane32_swap, and the exponentiated
 //     accumulator registers 8s..8s+7 ARE the B operand of O^T += V^T P^T for k-step s (k-slot permutation absorbed by the
 //     transposed V read) -- half the MFMA instructions per FLOP, 24 instead of 8 free VALU issue cycles under each MFMA;
-//   * the running maximum enters as the INITIAL accumulator (-m), Q is pre-scaled by scale*log2(e): a score costs one
-//     v_exp_f32 and one add -- no fma, no subtract; the O / l rescale happens only when a row's new scores exceed the
-//     running reference by 2^6 (wave-uniform branch; exact algebra, only the bf16 rounding point of P moves);
-//   * double-buffered K / V images (one barrier per key tile); the next tile's registers are written to the idle buffer
-//     between the softmax and the PV products, so the ds_write latency hides under the PV MFMAs;
-//   * K image pitch 144 B (b128 row reads conflict-free), V image pitch 192 B (the 4 x 16-column blocks of one transposed
-//     read land on the four 64-byte quarters of the 256-byte bank row: conflict-free).
+//   * the running reference -m enters as the C operand of the first k-step (`negm`, a register splat that changes only on a
+//     rescale), Q is pre-scaled by scale*log2(e): a score costs one v_exp_f32 and one add -- no fma, no subtract; the O / l
+//     rescale happens only when a row's new scores exceed the reference by 2^6 (wave-uniform branch; exact algebra, only
+//     the bf16 rounding point of P moves);
+//   * padded keys of a segment's ragged last tile leave the softmax through the matrix core: one extra k-step whose Q side is
+//     e_0 and whose K side holds -1e30 in slot 0 of every padded key (two MFMAs behind a scalar branch; written as
+//     compare/select pairs hipcc if-converts them into EVERY iteration: 60 VALU per tile);
+//   * fully masked rows (empty key segment, finite fill in the reference) run the same loop with a zero query;
+//   * double-buffered K / V images, one barrier per key tile; the next tile's registers are written to the idle buffer between
+//     the softmax and the PV products, so the ds_write latency hides under the PV MFMAs;
+//   * K image pitch 144 B (the 32x32x16 A-operand b128 row reads are conflict-free), V image pitch 192 B (the 4 rows x 2
+//     column blocks of one transposed read land on the four 64-byte quarters of the 256-byte bank row): SQ_LDS_BANK_CONFLICT 0.
+// Measured (tools/bench_attn.py, one process, B 256): 233-248 us against 240-262 us of the 16x16x32 kernel on the same box
+// (+3...+10 %).  Per-instruction counts fell by 2x (116 VALU + 16 MFMA per 32 x 64 score tile against 192 + 32), time did
+// not follow: the stamped build (variant 9, tools/probes/attn_stamps.py) shows a wave spending 10-11k cycles between its first
+// instruction and its first key tile -- ~2.8k until the segment table is in registers, ~6k until its (HBM-cold) Q rows and
+// first K/V tile have arrived, ~2k for the LDS staging and two barriers -- against ~2.8k cycles per key-tile iteration and 5
+// iterations per wave on average: block start-up latency, not the inner loop, bounds all three attention kernels at this
+// sequence length.  Tried on top and measured no gain (removed again): -m through an extra k-step instead of the splat (16
+// VGPRs fewer), 256-query tiles (QB 2: 255 VGPRs, -45 %), launch bounds for 3 / 4 waves per SIMD (spills), several query tiles
+// per block with an exact grid (no empty blocks, one segment-table round trip per block), samples in reverse order (Infinity
+// Cache), the segment table through scalar loads (slower: 32 serial K$ misses).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -684,8 +706,36 @@ template <int PITCH> struct Stage64 {
 
 #define FWD32_THR 6.0f    // log2 domain: P <= 2^6 between rescales
 
-template <int QB>
+// Diagnostic build (STAMP; variant 9 of mmae_internal.h, never the product path): per-wave s_memtime sums of where the time
+// goes -- [0] whole key loop, [1] inside the end-of-tile barrier, [2] in the register -> LDS staging block (its vmcnt wait),
+// [3] iterations, [4] kernel entry -> first iteration, [5] 1 per wave with work, [6] entry -> segment table in registers,
+// [7] -> Q rows and first K/V tile arrived.  One row per wave, plain stores (same-address atomics of 41k waves serialise for
+// milliseconds and distort everything they time); mmae_debug_mha_stamps() sums and clears them.
+#define STAMP_WAVES 131072
+__device__ unsigned long long g_mha_stamps[STAMP_WAVES][8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+extern "C" int mmae_debug_mha_stamps(unsigned long long* host8) {
+    if (!host8) return MMAE_ERR_ARG;
+    static unsigned long long* h = nullptr;
+    if (!h) h = new unsigned long long[(size_t)STAMP_WAVES * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mha_stamps), sizeof(unsigned long long) * STAMP_WAVES * 8) != hipSuccess) return MMAE_ERR_LAUNCH;
+    for (int i = 0; i < 8; ++i) host8[i] = 0;
+    for (size_t w = 0; w < STAMP_WAVES; ++w)
+        for (int i = 0; i < 8; ++i) host8[i] += h[w * 8 + i];
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_mha_stamps)) != hipSuccess) return MMAE_ERR_LAUNCH;
+    if (hipMemset(dptr, 0, sizeof(unsigned long long) * STAMP_WAVES * 8) != hipSuccess) return MMAE_ERR_LAUNCH;
+    return MMAE_OK;
+}
+
+template <int QB, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
+    unsigned long long t_entry = 0, t_seg = 0, t_q = 0, t_loop = 0, t_bar = 0, t_stage = 0;
+    if (STAMP) t_entry = stamp_now();
     constexpr int DH = 64, BM = 128 * QB, KP = 72, VP = 96;
     __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * KP];
     __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * VP];
@@ -699,6 +749,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
     const TileSel ts = pick_tile<BM>([&](int s) { return st.ql(s); }, p.nseg, bs.t);
     if (ts.seg < 0) return;
     const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t_seg = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
     const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
     int first_row = 0, first_n = 0;                               // tile 0, known to every wave without the shared list
     if (wave == 0) {
@@ -736,8 +787,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
             const bf16* qp = reinterpret_cast<const bf16*>(p.q) + (qrow0 + myq[qb]) * p.q_stride + h * DH + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                // fully masked rows (empty key segment, finite masked_fill in the reference) attend every key uniformly:
-                // a zero query gives every swept key the score 0 -- same loop, no special case
+                // a fully masked row attends every key uniformly: a zero query gives every swept key the score 0
                 qf[qb][ks] = (qvalid[qb] && !kp.uniform) ? ld8(qp + 16 * ks) : z8();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
@@ -756,6 +806,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
     }
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_q = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
     __syncthreads();                                               // tile list visible
     const int ntile = uni(tl_cnt);
     if (ntile > 0) {
@@ -769,18 +820,15 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
     }
     __syncthreads();
     const bf16* kbase = Ks[0] + r * KP + 8 * hh;
-    // Padded keys of a segment's ragged last tile (kn < 64; their K and V rows read as zeros) leave the softmax through the
-    // matrix core as well: one extra k-step whose Q side is the constant e_0 and whose K side holds -1e30 in slot 0 of every
-    // padded key adds -1e30 to exactly those scores.  Two MFMAs behind a scalar branch instead of 64 compare/select pairs
-    // (which hipcc if-converts into every iteration when they stand alone under the branch).
     bf16x8 qone = z8();
     if (hh == 0) qone[0] = (bf16)1.0f;
+    if (STAMP) t_loop = stamp_now();
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         const int kn = uni(tl_n[t]);
         const bf16* Kc = kbase + cur * (64 * KP);
         const bf16* Vc = Vs[cur];
-        // ---- S'^T = K Q~^T - m : the running reference enters as the C operand of the first k-step (negm: a register splat)
+        // ---- S'^T = K Q~^T - m : 2 key blocks x 4 k-steps, the first one seeded with -m
         f32x16 sacc[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -790,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mma32(kfr, qf[qb][ks], ks == 0 ? negm[qb] : sacc[qb][kb]);
             }
-        if (kn < 64) {
+        if (kn < 64) {                                             // ragged last tile of a segment (scalar branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 bf16x8 kmask = z8();
@@ -842,8 +890,11 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
         }
         // ---- the next tile's registers go to the idle buffer; the write latency hides under the PV products
         if (t + 1 < ntile) {
+            unsigned long long a = 0;
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); a = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             ixk.store(Ks[cur ^ 1], kreg);
             ixv.store(Vs[cur ^ 1], vreg);
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t_stage += stamp_now() - a; __builtin_amdgcn_sched_barrier(0); }
         }
         // ---- O^T += V^T P^T : 2 key blocks x 2 k-steps x 2 dh blocks
 #pragma unroll
@@ -856,11 +907,28 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = mma32(vfr, pb[qb][kb][s2], oacc[qb][d]);
                 }
-        __syncthreads();
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long a = stamp_now();
+            __syncthreads();
+            t_bar += stamp_now() - a;
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __syncthreads();
+        }
         if (t + 2 < ntile) {
             const long r2 = uni(tl_row[t + 2]); const int n2 = uni(tl_n[t + 2]);
             ixk.load(kg + r2 * p.k_stride, n2, kreg);
             ixv.load(vg + r2 * p.v_stride, n2, vreg);
+        }
+    }
+    if (STAMP) {
+        const unsigned long long t_end = stamp_now();
+        const unsigned w = blockIdx.x * 4 + wave;
+        if (lane == 0 && w < STAMP_WAVES) {
+            g_mha_stamps[w][0] = t_end - t_loop; g_mha_stamps[w][1] = t_bar; g_mha_stamps[w][2] = t_stage;
+            g_mha_stamps[w][3] = (unsigned long long)ntile; g_mha_stamps[w][4] = t_loop - t_entry; g_mha_stamps[w][5] = 1ull;
+            g_mha_stamps[w][6] = t_seg - t_entry; g_mha_stamps[w][7] = t_q - t_seg;
         }
     }
 #pragma unroll
@@ -887,22 +955,21 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 // `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
-    if (head_dim == 64 && (g_variant == 3 || g_variant == 4)) {   // 32x32x16 forward: 128- (QB 1) / 256-query (QB 2) tiles
+    if (head_dim == 64 && (g_variant == 0 || g_variant == 3 || g_variant == 4 || g_variant == 9)) {
+        // default (0 == 3): 32x32x16 forward, 4 waves x 32 queries = 128-query tiles; 4: 256-query tiles; 9: stamped diagnostic
         MhaDesc e = d;
-        if (g_variant == 3) {
-            e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
-            MMAE_LAUNCH((mha_bf16_fwd32_kernel<1>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
-        } else {
-            e.max_tiles = (d.max_tiles + 3) / 4 + d.nseg;
-            MMAE_LAUNCH((mha_bf16_fwd32_kernel<2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
-        }
-    } else if (head_dim == 64 && g_variant == 0) {           // default: 4 waves x 32 queries = 128-query tiles
+        e.max_tiles = g_variant == 4 ? (d.max_tiles + 3) / 4 + d.nseg : (d.max_tiles + 1) / 2 + d.nseg;
+        const dim3 grid(xcd_grid(e.B, e.H, e.max_tiles)), blk(256);
+        if (g_variant == 4) MMAE_LAUNCH((mha_bf16_fwd32_kernel<2>), grid, blk, 0, st, e);
+        else if (g_variant == 9) MMAE_LAUNCH((mha_bf16_fwd32_kernel<1, true>), grid, blk, 0, st, e);
+        else MMAE_LAUNCH((mha_bf16_fwd32_kernel<1>), grid, blk, 0, st, e);
+    } else if (head_dim == 64 && g_variant == 2) {           // round-1 kernel: 16x16x32, 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
     } else if (head_dim == 64 && g_variant == 8) {           // 8 waves x 16 queries (measured: no gain over 4 x 16)
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
-    } else {                                                 // variant 1 (dh 64) / dh 32: 4 waves x 16 queries
+    } else {                                                 // variant 1 (dh 64) / dh 32: 16x16x32, 4 waves x 16 queries
         dim3 grid(xcd_grid(d.B, d.H, d.max_tiles));
         if (head_dim == 64) MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4>), grid, dim3(256), 0, st, d);
         else MMAE_LAUNCH((mha_bf16_fwd_kernel<32, 4>), grid, dim3(256), 0, st, d);
@@ -914,7 +981,7 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int g_variant, hipStream_t st) {
     if (max_q_tiles > MAXT || max_k_tiles > MAXT) return MMAE_ERR_ARG;
     d.max_tiles = max_q_tiles;
-    if (head_dim == 64 && g_variant == 2) {                  // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
+    if (head_dim == 64 && g_variant == 22) {                 // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
         d.max_tiles = (max_q_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);
     } else if (head_dim == 64) MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);

@@ -21,6 +21,8 @@ int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const 
                          long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
                          const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                          int empty_mode, int variant, void* stream);
+/* diagnostic (variant 9 of the forward): copies the 8 per-launch stamp sums to host8 and clears them (host sync). */
+int mmae_debug_mha_stamps(unsigned long long* host8);
 #ifdef __cplusplus
 }
 #endif

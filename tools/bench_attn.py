@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--H", type=int, default=8)
 ap.add_argument("--dh", type=int, default=64)
-ap.add_argument("--variants", default="0")
+ap.add_argument("--variants", default="0", help="0: product kernels (dh 64 forward = 32x32x16), 2: round-1 16x16x32 forward, 4: 256-query tiles")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")

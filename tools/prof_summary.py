@@ -68,10 +68,12 @@ def pmc_json(fetch, write):
 def sq(path, steps, as_json=False):
     """Per-kernel and whole-step SQ view of `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
     SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py ...`.
-    MFMA-busy % of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): BUSY_CYCLES is summed over the chip's
-    256 x 4 SIMDs (it equals 16 x the 16x16x32 / 32 x the 32x32x16 MFMA count, MI355X_MICROARCH.md cycle constants),
-    GRBM_GUI_ACTIVE is the dispatch's length in shader clocks.  Whole step: sum of busy cycles / (1024 x sum of GUI_ACTIVE)
-    over every dispatch of the profiled steps (idle gaps between kernels are not in the denominator)."""
+    MFMA-busy % of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): BUSY_CYCLES is summed over the
+    chip's 256 x 4 SIMDs (it equals 16 x the 16x16x32 / 32 x the 32x32x16 MFMA count, MI355X_MICROARCH.md cycle constants --
+    checked on this data: BUSY / SQ_INSTS_MFMA = 16.0 for the 16x16x32 kernels); rocprofv3 reports GRBM_GUI_ACTIVE summed over
+    the 8 XCDs (GUI_ACTIVE / dispatch ns = 16-18.7, i.e. 8 x 2.0-2.33 GHz), so GUI/8 is the dispatch's length in shader clocks.
+    Whole step: sum of busy cycles / (1024 x sum of GUI/8) over every dispatch of the profiled steps (idle gaps between kernels
+    are not in the denominator).  The percentage is of ACTUAL shader cycles: TFLOP/s = busy % x 2.5 PF x (held clock / 2.4 GHz)."""
     import json
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
@@ -83,7 +85,7 @@ def sq(path, steps, as_json=False):
             seen.add((x["Dispatch_Id"], k))
             calls[k] += 1
             acc[k]["ns"] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
-    SIMDS = 1024.0
+    SIMDS = 1024.0 / 8.0          # per unit of the 8-XCD-summed GRBM_GUI_ACTIVE
     tot = collections.defaultdict(float)
     rows = []
     for k, c in acc.items():
@@ -95,6 +97,7 @@ def sq(path, steps, as_json=False):
                          valu_per_mfma=c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_MFMA"] if c.get("SQ_INSTS_MFMA") else None,
                          lds_conflict_pct=100.0 * c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
                          wait_pct=100.0 * c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                         clock_ghz=gui / 8.0 / c["ns"] if c["ns"] else None,
                          mfma_busy_cycles=c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), gui_active=gui))
     rows.sort(key=lambda r: -r["mfma_busy_cycles"])
     step = dict(mfma_busy_pct=round(100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * tot["GRBM_GUI_ACTIVE"]), 2) if tot["GRBM_GUI_ACTIVE"] else None,
@@ -103,18 +106,18 @@ def sq(path, steps, as_json=False):
     if as_json:
         print(json.dumps({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT "
                                     "SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 2 "
-                                    "--no-cpu-baseline --legs none (B=256); MFMA-busy = BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE)",
+                                    "--no-cpu-baseline --legs none (B=256); MFMA-busy = BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)",
                           "step": step, "kernels": {r["kernel"]: {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"}
                                                     for r in rows[:40]}}, indent=1))
         return
     print("whole step (all dispatches of %d profiled steps): MFMA-busy %.1f %% of the chip's SIMD cycles while a kernel runs; "
           "%.1f ms of kernels per step; %.3g VALU / %.3g MFMA instructions" % (steps, step["mfma_busy_pct"], step["kernel_ms_per_step"],
                                                                               tot["SQ_INSTS_VALU"], tot["SQ_INSTS_MFMA"]))
-    print("\n| kernel | calls | total ms | MFMA busy % | VALU / MFMA | LDS cycles conflicted % | wave cycles parked (s_waitcnt / barrier) % |\n|---|---|---|---|---|---|---|")
+    print("\n| kernel | calls | total ms | MFMA busy % | VALU / MFMA | LDS cycles conflicted % | wave cycles parked (s_waitcnt / barrier) % | clock GHz |\n|---|---|---|---|---|---|---|---|")
     f = lambda v, fmt="%.1f": "-" if v is None else fmt % v
     for r in rows[:24]:
-        print("| `%s` | %d | %.2f | %.1f | %s | %s | %s |" % (short(r["kernel"]), r["calls"], r["ms"], r["mfma_busy_pct"], f(r["valu_per_mfma"]),
-                                                               f(r["lds_conflict_pct"]), f(r["wait_pct"])))
+        print("| `%s` | %d | %.2f | %.1f | %s | %s | %s | %s |" % (short(r["kernel"]), r["calls"], r["ms"], r["mfma_busy_pct"], f(r["valu_per_mfma"]),
+                                                                    f(r["lds_conflict_pct"]), f(r["wait_pct"]), f(r["clock_ghz"], "%.2f")))
 
 
 if __name__ == "__main__":
