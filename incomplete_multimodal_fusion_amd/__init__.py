@@ -12,13 +12,14 @@ __version__ = "0.1.0"
 
 def install_as_multimae():
     """Register this package's `multimae` sub-package under the top-level name `multimae`, so that the reference driver's
-    own import lines (pretraining/pretrain_mmae.py:35-39: `from multimae.multimae_crossattn import ...`) resolve to the
+    own import lines (pretraining/pretrain_mmae.py:35-39: `from multimae.multimae_crossattn import ...`; the 4-modality
+    driver's pretrain_mmae_my.py:35-40: `from multimae.multimae_quadruplet import ...`) resolve to the
     native modules without editing the driver.  Call before the driver is imported."""
     import importlib
     import sys
     native = importlib.import_module(__name__ + ".multimae")
     sys.modules["multimae"] = native
     for sub in ("multimae_crossattn", "zorro_utils", "criterion", "input_adapters", "output_adapters_simple",
-                "multimae_utils"):
+                "multimae_utils", "multimae_quadruplet", "zorro_utils_quadruplet"):
         sys.modules["multimae." + sub] = importlib.import_module(__name__ + ".multimae." + sub)
     return native

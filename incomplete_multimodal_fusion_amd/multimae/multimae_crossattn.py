@@ -63,7 +63,12 @@ class MultiMAE(nn.Module):
                  num_fusion_tokens: int = 16,
                  return_token_types: Tuple[TokenTypes] = (TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION),
                  drop_path_rate: float = 0.0,
-                 norm_layer: nn.Module = LayerNorm):
+                 norm_layer: nn.Module = LayerNorm,
+                 fusion_blocks: bool = True,
+                 contrastive_tokens: bool = True):
+        """fusion_blocks / contrastive_tokens (keyword extras, default = this file's reference class): False builds the
+        sibling pretraining/multimae/multimae_quadruplet.py model -- same encoder without the per-layer Block_Fusion, without
+        mask_embedding and without the per-modality contrastive return tokens (see multimae_quadruplet.py here)."""
         super().__init__()
         assert drop_path_rate == 0.0, "stochastic depth is 0 on this path (reference default, pretrain_mmae.py:108)"
         for adapter in input_adapters.values():
@@ -95,13 +100,16 @@ class MultiMAE(nn.Module):
         self.return_tokens = nn.Parameter(trunc_normal_(torch.zeros(1, self.max_return_tokens, dim_tokens), std=0.02))
         self.attn_pool = Attention(dim=dim_tokens, dim_head=dim_head, heads=heads)
         self.fusion_tokens = nn.Parameter(trunc_normal_(torch.zeros(1, num_fusion_tokens, dim_tokens), std=0.02))
-        for d in self.domains:                                                # return_token_s1 / _s2 / _dem (:105-109)
-            setattr(self, 'return_token_' + d, nn.Parameter(torch.randn(1, 1, dim_tokens)))
+        self.has_fusion_blocks, self.has_contrastive_tokens = bool(fusion_blocks), bool(contrastive_tokens)
+        if contrastive_tokens:
+            for d in self.domains:                                            # return_token_s1 / _s2 / _dem (:105-109)
+                setattr(self, 'return_token_' + d, nn.Parameter(torch.randn(1, 1, dim_tokens)))
         self.mlp = Mlp(in_features=dim_tokens, hidden_features=int(dim_tokens * 4.0))
-        self.fus_blocks = nn.ModuleList([
-            Block_Fusion(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, norm_layer=norm_layer)
-            for _ in range(depth)])
-        self.mask_embedding = nn.Parameter(torch.zeros(1, num_fusion_tokens, dim_tokens))
+        if fusion_blocks:
+            self.fus_blocks = nn.ModuleList([
+                Block_Fusion(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, norm_layer=norm_layer)
+                for _ in range(depth)])
+            self.mask_embedding = nn.Parameter(torch.zeros(1, num_fusion_tokens, dim_tokens))
         self.blocks = nn.ModuleList([
             Block(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, drop_path=0.0, norm_layer=norm_layer)
             for _ in range(depth)])
@@ -244,7 +252,7 @@ class MultiMAE(nn.Module):
             xm = ops.gather_rows(pe_table.detach().contiguous(), desc.tok_pe)      # (B*N, D) fp32
         fus_pe = self.input_adapters['fusion'].posemb_rows()
         xf = (self.fusion_tokens[0] + fus_pe).unsqueeze(0).expand(B, P, D).reshape(BP, D).contiguous()
-        me = self.mask_embedding[0].contiguous()                                   # (P, D) shared rows
+        me = self.mask_embedding[0].contiguous() if self.has_fusion_blocks else None   # (P, D) shared rows
         # pending residual deltas (compute dtype): modality part / fusion part, as (tensor, row offset)
         dm, dm_off, df, df_off = tok, 0, None, -1
         tap_out = []
@@ -260,19 +268,24 @@ class MultiMAE(nn.Module):
 
         sw = self.side_stream_wgrad
         for l in range(self.depth):
-            fus, blk = self.fus_blocks[l], self.blocks[l]
-            # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) ---------------------------
-            dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
-            (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
-                                              fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
-            # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
-            kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
-            a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
-            o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
-            (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
-            f = ops.feedforward_geglu(y, fus.mlp[1].weight, fus.mlp[3].weight)                    # (BP, D)
+            blk = self.blocks[l]
+            if self.has_fusion_blocks:
+                fus = self.fus_blocks[l]
+                # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) -----------------------
+                dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
+                (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
+                                                  fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
+                # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
+                kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
+                a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
+                o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
+                (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
+                f = ops.feedforward_geglu(y, fus.mlp[1].weight, fus.mlp[3].weight)                    # (BP, D)
+                dl, o1, o2 = f, -1, 0
+            else:                                     # multimae_quadruplet.py:430-432: the Zorro-masked Block only
+                dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
             # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
-            (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
+            (xm, xf), z = ops.parts_add_ln([xm, xf], dl, [o1, o2], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
                                            out_dtype=T)                                     # (BN+BP, D)
             qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
@@ -378,6 +391,8 @@ class MultiMAE(nn.Module):
             preds[d] = PredTokens(tk, B, C, H, W, adapter.P_H) if self.fuse_unpatchify_loss else \
                 ops.unpatchify(tk, B, C, H, W, adapter.P_H)
 
+        if not self.has_contrastive_tokens:
+            return (preds, task_masks, return_tokens, ori_tokens, enc_fus)                  # multimae_quadruplet.py:490
         # ---- contrastive return tokens: one query per modality over the fusion tokens at its kept patches (:530-543) -----
         rt = torch.cat([getattr(self, 'return_token_' + d)[0] for d in doms], dim=0).contiguous()   # (M, D)
         cq = linear(ops.layernorm(rt, ap.norm.gamma, out_dtype=T), ap.to_q.weight)                  # (M, I)

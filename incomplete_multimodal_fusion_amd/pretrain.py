@@ -44,12 +44,14 @@ PRESETS = {'tiny': (192, 12, 3), 'small': (384, 12, 8), 'base': (768, 12, 8), 'l
 
 def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=None, patch_size: int = 16,
               input_size: int = 256, decoder_dim: int = 256, decoder_depth: int = 2, decoder_num_heads: int = 8,
-              dim_head: int = 64, domain_conf: Optional[dict] = None):
+              dim_head: int = 64, domain_conf: Optional[dict] = None, fusion_blocks: bool = True):
     """Adapters + model as get_model builds them (pretrain_mmae.py:193-246); `model` picks the size preset (the
     reference ignores --model and always builds the tiny factory, :239 -- SURVEY.md 0.5).  `domain_conf` defaults to the
-    3-modality table, or to the 4-modality one when 'dnw' is among the domains.  NOTE: the reference has no M = 4 model
-    WITH fusion blocks (multimae_quadruplet.py has none); that configuration is this package's extension of the
-    3-modality algorithm to M modalities and has no reference-generated fixture."""
+    3-modality table, or to the 4-modality one when 'dnw' is among the domains.
+    fusion_blocks=False builds the reference's own 4-modality model (multimae_quadruplet.MultiMAE, what
+    pretrain_mmae_my.py:248-255 builds: Zorro-masked blocks only, 5-tuple output; pinned by tests/golden/quad_tiny.npz).
+    NOTE: the reference has no M = 4 model WITH fusion blocks; fusion_blocks=True with four domains is this package's
+    extension of the 3-modality algorithm to M modalities and has no reference-generated fixture."""
     out_domains = tuple(in_domains) if out_domains is None else tuple(out_domains)
     conf = domain_conf or (DOMAIN_CONF_QUAD if 'dnw' in in_domains else DOMAIN_CONF)
 
@@ -79,9 +81,13 @@ def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=N
     else:
         from enum import Enum
         rtt = tuple(Enum('TokenTypesM', [(d.upper(), i) for i, d in enumerate(in_domains)] + [('FUSION', M)]))
-    return mc.MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters, num_global_tokens=1,
-                       dim_tokens=D, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4, num_fusion_tokens=P,
-                       return_token_types=rtt, drop_path_rate=0.0)
+    cls = mc.MultiMAE
+    if not fusion_blocks:
+        from .multimae import multimae_quadruplet
+        cls = multimae_quadruplet.MultiMAE
+    return cls(input_adapters=input_adapters, output_adapters=output_adapters, num_global_tokens=1,
+               dim_tokens=D, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4, num_fusion_tokens=P,
+               return_token_types=rtt, drop_path_rate=0.0)
 
 
 def make_loss_fns(out_domains=('s1', 's2', 'dem'), patch_size: int = 16, domain_conf: Optional[dict] = None):
@@ -143,8 +149,12 @@ def step_losses(out, tasks_dict: Dict[str, torch.Tensor], masks: Dict[str, torch
     """pretrain_mmae.py:479-500 with NoWeightingStrategy (utils/task_balancing.py:11-19) by default.
     contra='dino': sum_m dino_loss_func(return_token_m, pooled_m), weight 0.3 (pretrain_mmae.py:493,:500);
     contra='hardneg': HardNegtive_loss over every pair of the pooled return tokens (modalities + fusion), weight 1
-    (pretrain_mmae_s2dsm.py:482-492 written for M modalities)."""
+    (pretrain_mmae_s2dsm.py:482-492 written for M modalities);
+    contra='none': task losses only (pretrain_mmae_my.py:514-515) -- the only choice for the 5-tuple of the quadruplet model."""
     preds, _, pooled, _, _, *rets = out
+    if contra == 'dino' and not rets:
+        raise ValueError("contra='dino' needs the per-modality contrastive return tokens; this model returns none "
+                         "(multimae_quadruplet) -- use contra='none' or 'hardneg'")
     loss_fns = loss_fns or make_loss_fns(tuple(preds.keys()), patch_size)
     task_losses = {}
     for task in preds:
@@ -155,7 +165,9 @@ def step_losses(out, tasks_dict: Dict[str, torch.Tensor], masks: Dict[str, torch
         else:
             task_losses[task] = fn(pred, tasks_dict[task], mask=masks.get(task, None))
     feats = [f.squeeze(1) for f in torch.chunk(pooled, pooled.shape[1], dim=1)]   # :489-490 (squeeze the token axis)
-    if contra == 'dino':
+    if contra == 'none':
+        loss_contra, w = torch.zeros((), device=pooled.device), 0.0
+    elif contra == 'dino':
         loss_contra = sum(dino_loss_func(r.squeeze(1), f) for r, f in zip(rets, feats))          # :493
         w = 0.3 if contra_weight is None else contra_weight
     elif contra == 'hardneg':
@@ -163,7 +175,7 @@ def step_losses(out, tasks_dict: Dict[str, torch.Tensor], masks: Dict[str, torch
         loss_contra = sum(fn(feats[i], feats[j]) for i in range(len(feats)) for j in range(i + 1, len(feats)))
         w = 1.0 if contra_weight is None else contra_weight
     else:
-        raise ValueError("contra must be 'dino' or 'hardneg'")
+        raise ValueError("contra must be 'dino', 'hardneg' or 'none'")
     weighted = loss_balancer(task_losses) if loss_balancer is not None else task_losses
     loss = sum(weighted.values()) + w * loss_contra                                # :499-500
     return task_losses, loss_contra, loss

@@ -498,6 +498,79 @@ def gen_aux():
     print("aux.npz:", len(bag), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+def gen_quad():
+    """The reference's own 4-modality model (multimae_quadruplet.MultiMAE, no fusion blocks) under the loss of its driver
+    (pretrain_mmae_my.py:495-515: masked MSE / L1 / cross-entropy task losses, NoWeightingStrategy, no contrastive term):
+    forward 5-tuple, losses and every parameter gradient on explicit masks, plus one generate_random_masks call with its
+    recorded draws (the 4-modality version of masks.npz)."""
+    q = ref_loader.load_quad()
+    cfg = dict(dim_tokens=32, depth=2, dim_head=32, heads=2, image_size=64, patch_size=16, num_classes=9, dim_class_emb=8,
+               decoder_dim=32, decoder_depth=1, decoder_heads=1)
+    seeded()
+    model = ref_loader.build_reference_quad_model(q, **cfg)
+    gen = torch.Generator().manual_seed(1234)
+    rand_init_(model, gen, scale=0.3)
+    model.train()
+    B, P = 2, 16
+    x = {d: torch.randn(B, c, 64, 64, generator=gen) for d, c in ref_loader.QUAD_CHANNELS[:3]}
+    x["dnw"] = torch.randint(0, 9, (B, 64, 64), generator=gen)
+    bag = Bag()
+    bag["config"] = np.array(json.dumps(dict(cfg, B=B)))
+    for k, v in model.state_dict().items():
+        bag["state/" + k] = npy(v)
+    for d in x:
+        bag["x/" + d] = npy(x[d])
+    fns = {"s1": q.cr.MaskedMSELoss(patch_size=16, stride=1), "s2": q.cr.MaskedMSELoss(patch_size=16, stride=1),
+           "dem": q.cr.MaskedL1Loss(patch_size=16, stride=1),
+           "dnw": q.cr.MaskedCrossEntropyLoss(patch_size=16, stride=1, label_smoothing=0.0)}
+
+    def mask_case(keep):
+        m = {}
+        for d, idx in keep.items():
+            row = torch.ones(P, dtype=torch.long)
+            row[torch.tensor(idx, dtype=torch.long)] = 0
+            m[d] = row[None].repeat(B, 1)
+        return m
+    cases = {
+        "split": mask_case({"s1": [0, 3, 5, 6, 9, 10, 12], "s2": [1, 2, 4, 8, 11], "dem": [5, 6, 7, 9, 12, 3],
+                            "dnw": [0, 15, 14, 2, 7, 8]}),
+        "dropdnw": mask_case({"s1": list(range(0, 16, 2)), "s2": [1, 3, 5], "dem": list(range(4, 16)), "dnw": []}),
+    }
+    for cname, masks in cases.items():
+        N = int(sum((m[0] == 0).sum() for m in masks.values()))
+        model.zero_grad()
+        preds, tm, pooled, ori, fus = model(x, task_masks=masks, num_encoded_tokens=N)
+        task_losses = {t: fns[t](preds[t].float(), x[t], mask=masks.get(t, None)) for t in preds}
+        loss = sum(task_losses.values())
+        loss.backward()
+        pre = "case_%s/" % cname
+        bag[pre + "N"] = np.array(N)
+        for d in masks:
+            bag[pre + "mask/" + d] = npy(masks[d])
+            bag[pre + "pred/" + d] = npy(preds[d])
+            bag[pre + "task_loss/" + d] = npy(task_losses[d])
+        bag.put(pre[:-1], pooled=pooled, ori_tokens=ori, fusion_tokens=fus, loss=loss)
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                bag[pre + "grad/" + n] = npy(p.grad)
+    # generate_random_masks (multimae_quadruplet.py:177-250) with four modalities: replay the global-RNG draws
+    from torch.distributions.dirichlet import Dirichlet
+    toks = {d: torch.zeros(3, P, 4) for d in ("s1", "s2", "dem", "dnw")}
+    for i, (n_enc, alphas) in enumerate(((20, 1.0), (7, [0.3, 2.0, 1.0, 0.5]))):
+        torch.manual_seed(8800 + i)
+        tm, ids_keep, ids_restore = model.generate_random_masks(toks, n_enc, alphas=alphas, sample_tasks_uniformly=False)
+        torch.manual_seed(8800 + i)
+        al = [alphas] * 4 if isinstance(alphas, float) else alphas
+        dirichlet = Dirichlet(torch.Tensor(al)).sample((1,))
+        noise = torch.stack([torch.rand(1, P) for _ in range(4)])
+        noise_all = torch.rand(1, 4 * P)
+        bag.put("masks_%d" % i, n_enc=np.array(n_enc), alphas=np.array(al), dirichlet=dirichlet, noise=noise,
+                noise_all=noise_all, ids_keep=ids_keep, ids_restore=ids_restore, **{"mask_" + d: tm[d] for d in tm})
+    np.savez_compressed(os.path.join(OUT, "quad_tiny.npz"), **bag)
+    print("quad_tiny.npz:", len(bag), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # single-threaded reductions: the fixtures regenerate byte for byte
@@ -507,5 +580,6 @@ if __name__ == "__main__":
     gen_masks(ref)
     gen_downstream()
     gen_aux()
+    gen_quad()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

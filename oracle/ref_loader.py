@@ -187,3 +187,68 @@ def load_aux():
         ia=ref.ia, cr=ref.cr)
     _aux_cache = ns
     return ns
+
+
+_quad_cache = None
+
+
+def load_quad():
+    """The reference's own 4-modality model (pretraining/multimae/multimae_quadruplet.py with zorro_utils_quadruplet.py; what
+    pretraining/pretrain_mmae_my.py:35-36 imports), imported unmodified through the stub package of load().
+    zorro_utils_quadruplet.py:12-13 imports `beartype` (absent in this image) and never uses it: a placeholder module object
+    (identity decorator; beartype.typing = typing) is registered for the import only and removed again."""
+    global _quad_cache
+    if _quad_cache is not None:
+        return _quad_cache
+    ref = load()
+    import typing
+    saved = {k: v for k, v in sys.modules.items() if k == "multimae" or k.startswith("multimae.")}
+    for k in saved:
+        del sys.modules[k]
+    pkg = types.ModuleType("multimae")
+    pkg.__path__ = [MM]
+    sys.modules["multimae"] = pkg
+    sys.modules["multimae.multimae_utils"] = ref.mu
+    added = []
+    if "beartype" not in sys.modules:
+        bt = types.ModuleType("beartype")
+        bt.beartype = lambda f: f
+        bt.typing = typing
+        sys.modules["beartype"], sys.modules["beartype.typing"] = bt, typing
+        added = ["beartype", "beartype.typing"]
+    try:
+        ns = types.SimpleNamespace(zq=importlib.import_module("multimae.zorro_utils_quadruplet"),
+                                   mq=importlib.import_module("multimae.multimae_quadruplet"),
+                                   ia=ref.ia, oa=ref.oa, cr=ref.cr)
+    finally:
+        for k in added:
+            del sys.modules[k]
+        for k in [k for k in sys.modules if k == "multimae" or k.startswith("multimae.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    _quad_cache = ns
+    return ns
+
+
+QUAD_CHANNELS = (("s1", 2), ("s2", 4), ("dem", 1), ("dnw", 9))
+
+
+def build_reference_quad_model(q, *, dim_tokens, depth, dim_head, heads, image_size, patch_size=16, num_classes=9,
+                               dim_class_emb=64, decoder_dim=256, decoder_depth=2, decoder_heads=8):
+    """Adapters + multimae_quadruplet.MultiMAE the way pretraining/pretrain_mmae_my.py:46-81, :196-255 builds them
+    (s1 2ch, s2 4ch, dem 1ch, dnw class map with a SemSegInputAdapter and a num_classes-channel output adapter), free sizes."""
+    T = q.zq.TokenTypes
+    doms = [c[0] for c in QUAD_CHANNELS]
+    ia = {d: q.ia.PatchedInputAdapter(num_channels=c, stride_level=1, patch_size_full=patch_size, image_size=image_size)
+          for d, c in QUAD_CHANNELS[:3]}
+    ia["dnw"] = q.ia.SemSegInputAdapter(num_classes=num_classes, dim_class_emb=dim_class_emb, interpolate_class_emb=False,
+                                        stride_level=1, patch_size_full=patch_size, image_size=image_size)
+    oa = {d: q.oa.SpatialOutputAdapter(num_channels=(num_classes if d == "dnw" else c), stride_level=1,
+                                       patch_size_full=patch_size, dim_tokens=decoder_dim, depth=decoder_depth,
+                                       num_heads=decoder_heads, use_task_queries=True, task=d, context_tasks=list(doms),
+                                       use_xattn=True) for d, c in QUAD_CHANNELS}
+    ia["fusion"] = q.ia.FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=patch_size, image_size=image_size)
+    return q.mq.MultiMAE(input_adapters=ia, output_adapters=oa, num_global_tokens=1, dim_tokens=dim_tokens, depth=depth,
+                         dim_head=dim_head, heads=heads, ff_mult=4, num_fusion_tokens=(image_size // patch_size) ** 2,
+                         return_token_types=(T.S1, T.S2, T.DEM, T.DNW, T.FUSION), drop_path_rate=0.0,
+                         norm_layer=q.zq.LayerNorm)

@@ -116,7 +116,13 @@ def test_install_as_multimae_resolves_driver_imports():
         "from multimae.input_adapters import PatchedInputAdapter, FusionInputAdapter\n"
         "from multimae.output_adapters_simple import SpatialOutputAdapter\n"
         "assert pretrain_multimae_base.__module__.startswith('incomplete_multimodal_fusion_amd')\n"
-        "assert [t.value for t in T] == [0, 1, 2, 3]\n")
+        "assert [t.value for t in T] == [0, 1, 2, 3]\n"
+        # the 4-modality driver's lines (pretrain_mmae_my.py:35-40)
+        "from multimae.multimae_quadruplet import pretrain_multimae_base as qb, pretrain_multimae_tiny as qt\n"
+        "from multimae.zorro_utils_quadruplet import TokenTypes as TQ\n"
+        "from multimae.criterion import MaskedCrossEntropyLoss\n"
+        "from multimae.input_adapters import SemSegInputAdapter\n"
+        "assert qt.__module__.startswith('incomplete_multimodal_fusion_amd') and [t.value for t in TQ] == [0, 1, 2, 3, 4]\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
