@@ -95,6 +95,8 @@ def sq(path, steps, as_json=False):
         rows.append(dict(kernel=k, calls=calls[k], ms=c["ns"] / 1e6,
                          mfma_busy_pct=100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * gui) if gui else 0.0,
                          valu_per_mfma=c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_MFMA"] if c.get("SQ_INSTS_MFMA") else None,
+                         # per 16 MFMA-busy cycles = per 16x16x32-equivalent (a 32x32x16 instruction is two of them)
+                         valu_per_mfma16=16.0 * c.get("SQ_INSTS_VALU", 0.0) / c["SQ_VALU_MFMA_BUSY_CYCLES"] if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                          lds_conflict_pct=100.0 * c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
                          wait_pct=100.0 * c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
                          clock_ghz=gui / 8.0 / c["ns"] if c["ns"] else None,
@@ -113,10 +115,10 @@ def sq(path, steps, as_json=False):
     print("whole step (all dispatches of %d profiled steps): MFMA-busy %.1f %% of the chip's SIMD cycles while a kernel runs; "
           "%.1f ms of kernels per step; %.3g VALU / %.3g MFMA instructions" % (steps, step["mfma_busy_pct"], step["kernel_ms_per_step"],
                                                                               tot["SQ_INSTS_VALU"], tot["SQ_INSTS_MFMA"]))
-    print("\n| kernel | calls | total ms | MFMA busy % | VALU / MFMA | LDS cycles conflicted % | wave cycles parked (s_waitcnt / barrier) % | clock GHz |\n|---|---|---|---|---|---|---|---|")
+    print("\n| kernel | calls | total ms | MFMA busy % | VALU / MFMA instr | VALU / 16 MFMA-busy cycles (16x16x32-equivalents) | LDS cycles conflicted % | wave cycles parked (s_waitcnt / barrier) % | clock GHz |\n|---|---|---|---|---|---|---|---|---|")
     f = lambda v, fmt="%.1f": "-" if v is None else fmt % v
     for r in rows[:24]:
-        print("| `%s` | %d | %.2f | %.1f | %s | %s | %s | %s |" % (short(r["kernel"]), r["calls"], r["ms"], r["mfma_busy_pct"], f(r["valu_per_mfma"]),
+        print("| `%s` | %d | %.2f | %.1f | %s | %s | %s | %s | %s |" % (short(r["kernel"]), r["calls"], r["ms"], r["mfma_busy_pct"], f(r["valu_per_mfma"]), f(r["valu_per_mfma16"]),
                                                                     f(r["lds_conflict_pct"]), f(r["wait_pct"]), f(r["clock_ghz"], "%.2f")))
 
 
