@@ -27,9 +27,10 @@ import torch.distributed as dist
 
 def init_distributed(backend: Optional[str] = None) -> bool:
     """env:// rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (utils/dist.py:62-93).  Returns True when a
-    process group with world_size > 1 is active."""
+    process group with world_size > 1 is active.  MMAE_DIST_SINGLE_RANK=1 also forms the group for WORLD_SIZE = 1 (the
+    one-GPU rehearsal of the RCCL path: same backend, collectives, streams and reducer as N > 1, tests/test_gpu_dp_engine.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not ("RANK" in os.environ and os.environ.get("MMAE_DIST_SINGLE_RANK") == "1"):
         return False
     if not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL over xGMI needs it on this driver

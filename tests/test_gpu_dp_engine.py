@@ -81,3 +81,32 @@ def test_two_ranks_engine_flat_allreduce_matches_average_of_single_process_gradi
             assert torch.allclose(got, want, rtol=1e-4, atol=1e-6 + 1e-4 * float(want.abs().max())), (rank, n)
     for n in out[0][2]:                                               # same update on both ranks
         assert out[0][2][n] == out[1][2][n], n
+
+
+def test_bench_step_over_rccl_single_rank_matches_the_undistributed_step():
+    """The N > 1 code path on real RCCL with the one GPU this box has: bench.py under torch.distributed.run with ONE rank and
+    MMAE_DIST_SINGLE_RANK=1 -- backend "nccl" (= RCCL), GradAllReducer over the engine's flat gradient buffer with
+    ReduceOp.AVG launched from the backward hooks on RCCL's stream, barrier + MAX-over-ranks timing -- must run and give the
+    same loss trajectory as the same seeds without a process group (a world-1 average is the identity)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--legs", "none",
+              "--tunable", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MMAE_DIST_BACKEND", None)
+    plain = subprocess.run([sys.executable] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ranked = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port)] + common, cwd=root,
+                            env=dict(env, MMAE_DIST_SINGLE_RANK="1"), capture_output=True, text=True, timeout=600)
+    assert ranked.returncode == 0, ranked.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in ranked.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["backend"] == "none" and b["backend"] == "nccl" and b["ranks"] == 1 and b["n_gpus"] == 1
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"]), (a["config"]["loss"], b["config"]["loss"])
