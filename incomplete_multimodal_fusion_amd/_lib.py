@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmae_hip.so")
+LIB_PATH = os.environ.get("MMAE_HIP_LIB") or os.path.join(_HERE, "csrc", "libmmae_hip.so")   # env: A/B runs of another build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmae_hip.h")
 INTERNAL_HEADER_PATH = os.path.join(_HERE, "csrc", "mmae_internal.h")      # test / tuning entry points, not the product ABI
 

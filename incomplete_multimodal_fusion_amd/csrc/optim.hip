@@ -38,25 +38,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     const float inv_bc1 = 1.f / (1.f - powf(b1, (float)step));
     const float inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, (float)step));
-    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const long stride = (long)gridDim.x * 256 * 4;
-    for (long i = i0; i < n; i += stride) {
-        f32x4 P = *reinterpret_cast<const f32x4*>(p + i);
-        f32x4 G = *reinterpret_cast<const f32x4*>(g + i) * grad_scale;
-        f32x4 M = *reinterpret_cast<const f32x4*>(m + i);
-        f32x4 V = *reinterpret_cast<const f32x4*>(v + i);
-        P *= (1.f - lr * wd);
-        M = M * b1 + G * (1.f - b1);
-        V = V * b2 + G * G * (1.f - b2);
+    // one pass (block b owns elements [1024 b, 1024 b + 1024)), streaming accesses: the five buffers are touched once per step
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 P = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
+    f32x4 G = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i)) * grad_scale;
+    f32x4 M = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i));
+    f32x4 V = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i));
+    P *= (1.f - lr * wd);
+    M = M * b1 + G * (1.f - b1);
+    V = V * b2 + G * G * (1.f - b2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) P[j] -= (lr * inv_bc1) * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
-        *reinterpret_cast<f32x4*>(p + i) = P;
-        *reinterpret_cast<f32x4*>(m + i) = M;
-        *reinterpret_cast<f32x4*>(v + i) = V;
-        if (shadow) {
-            bf16x4 s; s[0] = (bf16)P[0]; s[1] = (bf16)P[1]; s[2] = (bf16)P[2]; s[3] = (bf16)P[3];
-            *reinterpret_cast<bf16x4*>(shadow + i) = s;
-        }
+    for (int j = 0; j < 4; ++j) P[j] -= (lr * inv_bc1) * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
+    __builtin_nontemporal_store(P, reinterpret_cast<f32x4*>(p + i));
+    __builtin_nontemporal_store(M, reinterpret_cast<f32x4*>(m + i));
+    __builtin_nontemporal_store(V, reinterpret_cast<f32x4*>(v + i));
+    if (shadow) {
+        bf16x4 s; s[0] = (bf16)P[0]; s[1] = (bf16)P[1]; s[2] = (bf16)P[2]; s[3] = (bf16)P[3];
+        *reinterpret_cast<bf16x4*>(shadow + i) = s;
     }
 }
 
@@ -151,7 +150,9 @@ static int adamw_launch(long n, float* p, const float* g, float* m, float* v, vo
                         void* stream) {
     if (n < 0 || (n % 4) || !p || !g || !m || !v || step < 1) return MMAE_ERR_ARG;
     if (n == 0) return MMAE_OK;
-    MMAE_LAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
+    const long nb = (n / 4 + 255) / 256;
+    if (nb > 0x7fffffffL) return MMAE_ERR_ARG;
+    MMAE_LAUNCH(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
                        reinterpret_cast<bf16*>(shadow_bf16), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ctl);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;

@@ -22,6 +22,23 @@ template <> __device__ __forceinline__ void st4f<bf16>(bf16* p, const f32x4& v) 
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// streaming (nontemporal) forms for the token-row tensors: each is touched once per kernel and is 0.25-0.5 GB
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f32x4 ld4s(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4s<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+template <> __device__ __forceinline__ f32x4 ld4s<bf16>(const bf16* p) {
+    union { u32x2 q; bf16 e[4]; } u;
+    u.q = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return f32x4{(float)u.e[0], (float)u.e[1], (float)u.e[2], (float)u.e[3]};
+}
+template <typename T> __device__ __forceinline__ void st4s(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void st4s<float>(float* p, const f32x4& v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+template <> __device__ __forceinline__ void st4s<bf16>(bf16* p, const f32x4& v) {
+    union { u32x2 q; bf16 e[4]; } u;
+    u.e[0] = (bf16)v[0]; u.e[1] = (bf16)v[1]; u.e[2] = (bf16)v[2]; u.e[3] = (bf16)v[3];
+    __builtin_nontemporal_store(u.q, reinterpret_cast<u32x2*>(p));
+}
+
 __device__ __forceinline__ float sum4(const f32x4& v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // ------------------------------------------------------------------------------------------ add + LayerNorm(x2) forward
@@ -46,9 +63,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(AddLnFwd p) {
         const int col = 4 * (lane + 64 * c);
         v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (col < D) {
-            v[c] = ld4f<float>(p.x + row * D + col);
-            if (p.delta) v[c] += ld4f<TD>(reinterpret_cast<const TD*>(p.delta) + row * D + col);
-            if (p.x_new) st4f<float>(p.x_new + row * D + col, v[c]);
+            v[c] = ld4s<float>(p.x + row * D + col);
+            if (p.delta) v[c] += ld4s<TD>(reinterpret_cast<const TD*>(p.delta) + row * D + col);
+            if (p.x_new) st4s<float>(p.x_new + row * D + col, v[c]);
             s += sum4(v[c]);
         }
     }
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(AddLnFwd p) {
                 o = (o - m2) * r2 * ld4f<float>(p.g2 + col);
                 if (p.b2) o += ld4f<float>(p.b2 + col);
             }
-            st4f<TY>(reinterpret_cast<TY*>(p.y) + row * D + col, o);
+            st4s<TY>(reinterpret_cast<TY*>(p.y) + row * D + col, o);
         }
     }
     if (lane == 0) *reinterpret_cast<f32x4*>(p.stats + row * 4) = f32x4{m1, r1, m2, r2};
@@ -140,8 +157,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
             const int col = 4 * (lane + 64 * c);
             xh[c] = z4; gv[c] = z4;
             if (col < D) {
-                xh[c] = (ld4f<float>(p.x_new + row * D + col) - m1) * r1;
-                const f32x4 gy = ld4f<TY>(reinterpret_cast<const TY*>(p.gy) + row * D + col);
+                xh[c] = (ld4s<float>(p.x_new + row * D + col) - m1) * r1;
+                const f32x4 gy = ld4s<TY>(reinterpret_cast<const TY*>(p.gy) + row * D + col);
                 if (DOUBLE) {
                     const f32x4 G1 = *reinterpret_cast<const f32x4*>(sg1 + col);
                     f32x4 u = xh[c] * G1;
@@ -187,9 +204,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(AddLnBwd p) {
             const int col = 4 * (lane + 64 * c);
             if (col < D) {
                 f32x4 gx = (gv[c] - c3 - xh[c] * c4) * r1;
-                if (p.gx_up) gx += ld4f<float>(p.gx_up + row * D + col);
-                if (p.gx) st4f<float>(p.gx + row * D + col, gx);
-                if (p.gdelta) st4f<TD>(reinterpret_cast<TD*>(p.gdelta) + row * D + col, gx);
+                if (p.gx_up) gx += ld4s<float>(p.gx_up + row * D + col);
+                if (p.gx) st4s<float>(p.gx + row * D + col, gx);
+                if (p.gdelta) st4s<TD>(reinterpret_cast<TD*>(p.gdelta) + row * D + col, gx);
             }
         }
     }
@@ -345,92 +362,140 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
     r.pdf = 0.39894228040143268f * e;
     return r;
 }
-template <typename T, int V> __device__ __forceinline__ void ldv(const T* p, float* o) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// NT: nontemporal (streaming) access -- these tensors are touched once per kernel and are far larger than the caches
+template <typename T, int V, bool NT = false> __device__ __forceinline__ void ldv(const T* p, float* o) {
     if constexpr (V == 1) o[0] = to_f(p[0]);
-    else if constexpr (sizeof(T) == 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    else {
+        union { u32x4 q; float f[4]; bf16 e[8]; } u;
+        if constexpr (NT) u.q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        else u.q = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = v[j];
-    } else {
-        union { uint4 q; bf16 e[8]; } u;
-        u.q = *reinterpret_cast<const uint4*>(p);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (float)u.e[j];
+        for (int j = 0; j < V; ++j) { if constexpr (sizeof(T) == 4) o[j] = u.f[j]; else o[j] = (float)u.e[j]; }
     }
 }
-template <typename T, int V> __device__ __forceinline__ void stv(T* p, const float* o) {
+template <typename T, int V, bool NT = false> __device__ __forceinline__ void stv(T* p, const float* o) {
     if constexpr (V == 1) p[0] = from_f<T>(o[0]);
-    else if constexpr (sizeof(T) == 4) {
-        f32x4 v;
+    else {
+        union { u32x4 q; float f[4]; bf16 e[8]; } u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = o[j];
-        *reinterpret_cast<f32x4*>(p) = v;
-    } else {
-        union { uint4 q; bf16 e[8]; } u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) u.e[j] = (bf16)o[j];
-        *reinterpret_cast<uint4*>(p) = u.q;
+        for (int j = 0; j < V; ++j) { if constexpr (sizeof(T) == 4) u.f[j] = o[j]; else u.e[j] = (bf16)o[j]; }
+        if constexpr (NT) __builtin_nontemporal_store(u.q, reinterpret_cast<u32x4*>(p));
+        else *reinterpret_cast<u32x4*>(p) = u.q;
     }
 }
+// Launch shape of the elementwise kernels: ONE pass -- block b owns the EW_U * 256 consecutive vectors starting at
+// b * EW_U * 256, no grid-stride loop -- with nontemporal 16-byte accesses.  Measured at rows = 163840, F = 2048
+// (tools/probes/geglu_stream_probe.hip): a 4096-block grid-stride loop moves 4.7 TB/s (blocks in flight touch addresses
+// 16 MB apart), one pass 5.7-5.9, one pass + nontemporal 6.05-6.16 TB/s (torch's elementwise add on this chip: 6.25).
 // V = elements per lane: 16 / sizeof(T) when the row width is a multiple of it, else 1
-template <typename T, int V>
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int F) {
-    const int per_row = F / V;
-    const long n = rows * per_row;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / per_row;
-        const int c = (int)(i - r * per_row) * V;
-        const T* hv = h + r * 2 * F + c;
-        float val[V], gate[V], o[V];
-        ldv<T, V>(hv, val); ldv<T, V>(hv + F, gate);
-#pragma unroll
-        for (int j = 0; j < V; ++j) o[j] = gate[j] * gelu_parts(gate[j]).cdf * val[j];
-        stv<T, V>(out + r * F + c, o);
-    }
+constexpr int EW_U = 2;
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static long ew_blocks(long n) { long b = (n + 256L * EW_U - 1) / (256L * EW_U); return b < 1 ? 1 : b; }
+static int log2_exact(long v) { int s = 0; while ((1L << s) < v) ++s; return (1L << s) == v ? s : -1; }
+__device__ __forceinline__ void ew_row_col(long i, int per_row, int sh, long& r, int& c) {
+    r = sh >= 0 ? (i >> sh) : i / per_row;                 // wave-uniform choice; the bench widths are powers of two
+    c = (int)(i - r * per_row);
 }
 template <typename T, int V>
-__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ g, T* __restrict__ dh, long rows, int F) {
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int F, int sh) {
+    constexpr bool NT = V > 1;
     const int per_row = F / V;
     const long n = rows * per_row;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / per_row;
-        const int c = (int)(i - r * per_row) * V;
-        const T* hv = h + r * 2 * F + c;
-        T* dv = dh + r * 2 * F + c;
-        float val[V], gate[V], gg[V], dval[V], dgate[V];
-        ldv<T, V>(hv, val); ldv<T, V>(hv + F, gate); ldv<T, V>(g + r * F + c, gg);
+    const long base = (long)blockIdx.x * (256 * EW_U) + threadIdx.x;
+    float val[EW_U][V], gate[EW_U][V];
+    long r[EW_U]; int c[EW_U];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const GeluParts gp = gelu_parts(gate[j]);
-            dval[j] = gg[j] * gate[j] * gp.cdf;
-            dgate[j] = gg[j] * val[j] * fmaf(gate[j], gp.pdf, gp.cdf);
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + u * 256;
+        if (i < n) {
+            ew_row_col(i, per_row, sh, r[u], c[u]);
+            const T* hv = h + r[u] * 2 * F + c[u] * V;
+            ldv<T, V, NT>(hv, val[u]); ldv<T, V, NT>(hv + F, gate[u]);
         }
-        stv<T, V>(dv, dval); stv<T, V>(dv + F, dgate);
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        if (base + u * 256 < n) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = gate[u][j] * gelu_parts(gate[u][j]).cdf * val[u][j];
+            stv<T, V, NT>(out + r[u] * F + c[u] * V, o);
+        }
     }
 }
+template <typename T, int V>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ g, T* __restrict__ dh, long rows, int F, int sh) {
+    constexpr bool NT = V > 1;
+    const int per_row = F / V;
+    const long n = rows * per_row;
+    const long base = (long)blockIdx.x * (256 * EW_U) + threadIdx.x;
+    float val[EW_U][V], gate[EW_U][V], gg[EW_U][V];
+    long r[EW_U]; int c[EW_U];
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + u * 256;
+        if (i < n) {
+            ew_row_col(i, per_row, sh, r[u], c[u]);
+            const T* hv = h + r[u] * 2 * F + c[u] * V;
+            ldv<T, V, NT>(hv, val[u]); ldv<T, V, NT>(hv + F, gate[u]); ldv<T, V, NT>(g + r[u] * F + c[u] * V, gg[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        if (base + u * 256 < n) {
+            float dval[V], dgate[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const GeluParts gp = gelu_parts(gate[u][j]);
+                dval[j] = gg[u][j] * gate[u][j] * gp.cdf;
+                dgate[j] = gg[u][j] * val[u][j] * fmaf(gate[u][j], gp.pdf, gp.cdf);
+            }
+            T* dv = dh + r[u] * 2 * F + c[u] * V;
+            stv<T, V, NT>(dv, dval); stv<T, V, NT>(dv + F, dgate);
+        }
+    }
+}
+// n = number of elements, a multiple of V
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
-    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (long)gridDim.x * blockDim.x * V) {
-        float v[V], o[V];
-        ldv<T, V>(x + i, v);
+    constexpr bool NT = V > 1;
+    const long base = ((long)blockIdx.x * (256 * EW_U) + threadIdx.x) * V;
+    float v[EW_U][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) o[j] = v[j] * gelu_parts(v[j]).cdf;
-        stv<T, V>(y + i, o);
+    for (int u = 0; u < EW_U; ++u) if (base + (long)u * 256 * V < n) ldv<T, V, NT>(x + base + (long)u * 256 * V, v[u]);
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + (long)u * 256 * V;
+        if (i < n) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = v[u][j] * gelu_parts(v[u][j]).cdf;
+            stv<T, V, NT>(y + i, o);
+        }
     }
 }
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ dx, long n) {
-    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (long)gridDim.x * blockDim.x * V) {
-        float v[V], gg[V], o[V];
-        ldv<T, V>(x + i, v); ldv<T, V>(g + i, gg);
+    constexpr bool NT = V > 1;
+    const long base = ((long)blockIdx.x * (256 * EW_U) + threadIdx.x) * V;
+    float v[EW_U][V], gg[EW_U][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const GeluParts gp = gelu_parts(v[j]); o[j] = gg[j] * fmaf(v[j], gp.pdf, gp.cdf); }
-        stv<T, V>(dx + i, o);
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + (long)u * 256 * V;
+        if (i < n) { ldv<T, V, NT>(x + i, v[u]); ldv<T, V, NT>(g + i, gg[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + (long)u * 256 * V;
+        if (i < n) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const GeluParts gp = gelu_parts(v[u][j]); o[j] = gg[u][j] * fmaf(v[u][j], gp.pdf, gp.cdf); }
+            stv<T, V, NT>(dx + i, o);
+        }
     }
 }
-
-static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static int ew_grid(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1; return (int)b; }
 
 extern "C" int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream) {
     if (!ok_dtype(dtype) || rows < 0 || F <= 0 || !h || !out) return MMAE_ERR_ARG;
@@ -438,8 +503,10 @@ extern "C" int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int V = dtype == MMAE_BF16 ? 8 : 4;
     const bool vec = (F % V) == 0 && al16(h) && al16(out);
-    const long n = rows * (vec ? F / V : F);
-#define GO(T, V) MMAE_LAUNCH((geglu_fwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (T*)out, rows, F)
+    const long per_row = vec ? F / V : F, n = rows * per_row;
+    if (ew_blocks(n) > 0x7fffffffL) return MMAE_ERR_ARG;
+    const int sh = log2_exact(per_row);
+#define GO(T, V) MMAE_LAUNCH((geglu_fwd_kernel<T, V>), dim3((unsigned)ew_blocks(n)), dim3(256), 0, st, (const T*)h, (T*)out, rows, F, sh)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -451,8 +518,10 @@ extern "C" int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int V = dtype == MMAE_BF16 ? 8 : 4;
     const bool vec = (F % V) == 0 && al16(h) && al16(gout) && al16(dh);
-    const long n = rows * (vec ? F / V : F);
-#define GO(T, V) MMAE_LAUNCH((geglu_bwd_kernel<T, V>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)h, (const T*)gout, (T*)dh, rows, F)
+    const long per_row = vec ? F / V : F, n = rows * per_row;
+    if (ew_blocks(n) > 0x7fffffffL) return MMAE_ERR_ARG;
+    const int sh = log2_exact(per_row);
+#define GO(T, V) MMAE_LAUNCH((geglu_bwd_kernel<T, V>), dim3((unsigned)ew_blocks(n)), dim3(256), 0, st, (const T*)h, (const T*)gout, (T*)dh, rows, F, sh)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -463,7 +532,8 @@ extern "C" int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* st
     if (n == 0) return MMAE_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = (n % (dtype == MMAE_BF16 ? 8 : 4)) == 0 && al16(x) && al16(y);
-#define GO(T, V) MMAE_LAUNCH((gelu_fwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (T*)y, n)
+    if (ew_blocks(n) > 0x7fffffffL) return MMAE_ERR_ARG;
+#define GO(T, V) MMAE_LAUNCH((gelu_fwd_kernel<T, V>), dim3((unsigned)ew_blocks(n / V)), dim3(256), 0, st, (const T*)x, (T*)y, n)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();
@@ -474,7 +544,8 @@ extern "C" int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, vo
     if (n == 0) return MMAE_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = (n % (dtype == MMAE_BF16 ? 8 : 4)) == 0 && al16(x) && al16(g) && al16(dx);
-#define GO(T, V) MMAE_LAUNCH((gelu_bwd_kernel<T, V>), dim3(ew_grid(n / V)), dim3(256), 0, st, (const T*)x, (const T*)g, (T*)dx, n)
+    if (ew_blocks(n) > 0x7fffffffL) return MMAE_ERR_ARG;
+#define GO(T, V) MMAE_LAUNCH((gelu_bwd_kernel<T, V>), dim3((unsigned)ew_blocks(n / V)), dim3(256), 0, st, (const T*)x, (const T*)g, (T*)dx, n)
     if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
 #undef GO
     MMAE_CHECK_LAUNCH();

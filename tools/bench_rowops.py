@@ -48,6 +48,57 @@ def main():
     t_b = timeit(lambda: call("mmae_gelu_bwd", 1, x.numel(), ptr(x), ptr(gx), ptr(dx), stream()))
     print("            gelu_fwd %.1f us (%.2f TB/s)   gelu_bwd %.1f us (%.2f TB/s)" %
           (t_f, x.numel() * 4 / t_f / 1e6, t_b, x.numel() * 6 / t_b / 1e6))
+    add_ln(args, call, ptr, stream, _lib.lib())
+    modattn(args)
+
+
+def add_ln(args, call, ptr, stream, lib):
+    """The encoder's residual add + double LayerNorm at the bench shape (rows x 768, bf16 delta / y, fp32 stream)."""
+    dev, rows, D = "cuda:0", args.rows, 768
+    x = torch.randn(rows, D, device=dev); delta = torch.randn(rows, D, device=dev).to(torch.bfloat16)
+    xn = torch.empty_like(x); y = torch.empty(rows, D, device=dev, dtype=torch.bfloat16)
+    g1 = torch.rand(D, device=dev) + 0.5; g2 = torch.rand(D, device=dev) + 0.5
+    stats = torch.empty(rows, 4, device=dev)
+    fwd = lambda: call("mmae_add_ln_fwd", 1, 1, rows, D, ptr(x), ptr(delta), ptr(xn), ptr(y), ptr(g1), None, 1e-5, ptr(g2), None,
+                       1e-5, ptr(stats), stream())
+    t_f = timeit(fwd)
+    gy = torch.randn(rows, D, device=dev).to(torch.bfloat16); gup = torch.randn(rows, D, device=dev)
+    gx = torch.empty_like(x); gd = torch.empty_like(delta)
+    ws = torch.empty(lib.mmae_add_ln_bwd_ws_floats(rows, D), device=dev)
+    dg1 = torch.zeros(D, device=dev); dg2 = torch.zeros(D, device=dev)
+    bwd = lambda: call("mmae_add_ln_bwd", 1, 1, rows, D, ptr(xn), ptr(gy), ptr(gup), ptr(g1), None, ptr(g2), ptr(stats), ptr(gx),
+                       ptr(gd), ptr(dg1), None, ptr(dg2), None, ptr(ws), 0, stream())
+    t_b = timeit(bwd)
+    bf, bb = rows * D * (4 + 2 + 4 + 2), rows * D * (4 + 2 + 4 + 4 + 2)
+    print("            add_ln_fwd %.1f us (%.2f TB/s)   add_ln_bwd (gx_up, gx, gdelta) %.1f us (%.2f TB/s)" %
+          (t_f, bf / t_f / 1e6, t_b, bb / t_b / 1e6))
+
+
+def modattn(args):
+    """Modality attention of Block_Fusion at the bench shape: B = 256, P = 256, M + 1 = 4 slots, I = 512, a slot is a kept
+    token row with probability 1/2, else the patch's shared mask-embedding row."""
+    from incomplete_multimodal_fusion_amd import ops
+    dev, B, P, ns, H, dh = "cuda:0", 256, 256, 4, 8, 64
+    I = H * dh
+    BN, BP = B * 384, B * P
+    g = torch.Generator(device="cpu").manual_seed(0)
+    kv = torch.randn(BN + BP + P, 2 * I, device=dev).to(torch.bfloat16).requires_grad_()
+    q = torch.randn(BP, I, device=dev).to(torch.bfloat16).requires_grad_()
+    shared = BN + BP
+    slot = torch.empty(BP, ns, dtype=torch.int32)
+    tok = torch.randperm(BN, generator=g)[:BP * (ns - 1)].reshape(BP, ns - 1).to(torch.int32) if BN >= BP * (ns - 1) else \
+        torch.randint(0, BN, (BP, ns - 1), generator=g, dtype=torch.int32)
+    keep = torch.rand(BP, ns - 1, generator=g) < 0.5
+    pidx = (torch.arange(BP) % P).to(torch.int32)[:, None]
+    slot[:, :ns - 1] = torch.where(keep, tok, shared + pidx)
+    slot[:, ns - 1] = BN + torch.arange(BP, dtype=torch.int32)
+    slot = slot.to(dev)
+    with torch.no_grad():
+        t_f = timeit(lambda: ops.modattn(q, kv, slot, B, P, ns, H, dh, shared, dh ** -0.5))
+    out = ops.modattn(q, kv, slot, B, P, ns, H, dh, shared, dh ** -0.5)
+    go = torch.randn_like(out)
+    t_b = timeit(lambda: torch.autograd.grad(out, (q, kv), go, retain_graph=True))
+    print("            modattn_fwd %.1f us   modattn bwd (incl. finish) %.1f us" % (t_f, t_b))
 
 
 if __name__ == "__main__":
