@@ -188,12 +188,13 @@ def mfma_busy():
 def event_bracket_overhead_ms(device, n=96):
     """What a HIP-event bracket measures around NOTHING on a busy stream: the two event packets are each processed after
     the preceding work drains, so every bracket of ops.KernelTimer carries this constant on top of the kernel's own
-    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms GEMM keeps the queue
-    busy, then an empty bracket -- and subtracted from the roofline legs' averages; both figures are printed."""
-    a = torch.randn(2048, 2048, device=device, dtype=torch.bfloat16)
+    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms elementwise kernel
+    keeps the queue busy (not a GEMM: TunableOp would tune the new shape), then an empty bracket -- and subtracted from the
+    roofline legs' averages; both figures are printed."""
+    a = torch.zeros(64 << 20, device=device, dtype=torch.float32)
     pairs = []
     for _ in range(n):
-        torch.mm(a, a)
+        a.add_(1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()
         pairs.append((e0, e1))
