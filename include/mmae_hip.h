@@ -75,6 +75,19 @@ int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, const float*
                     const float* stats, float* gx, void* gdelta, float* dgamma1, float* dbeta1, float* dgamma2,
                     float* dbeta2, float* ws, int accumulate, void* stream);
 
+/* Two double LayerNorms of the SAME residual rows in one pass: path a = Block_Fusion's (norm1, attn.norm) for the modality
+ * attention's K/V, path b = Block's (norm1, attn.norm) for the Zorro attention (MM/multimae_crossattn.py:454-470 with
+ * DSI-MM/zorro_utils.py:238, :255; the modality rows are not changed between the two).  Bias-less LayerNorms only.
+ * Same results as two mmae_add_ln_fwd / mmae_add_ln_bwd calls (the first with delta, the second without). */
+int mmae_add_ln_fwd_dual(int dtype_delta, int dtype_y, long rows, int D, const float* x, const void* delta, float* x_new,
+                         void* y_a, void* y_b, const float* gamma1_a, const float* gamma2_a, const float* gamma1_b,
+                         const float* gamma2_b, float eps1, float eps2, float* stats_a, float* stats_b, void* stream);
+int mmae_add_ln_bwd_dual(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy_a,
+                         const void* gy_b, const float* gx_up, const float* gamma1_a, const float* gamma2_a,
+                         const float* gamma1_b, const float* gamma2_b, const float* stats_a, const float* stats_b,
+                         float* gx, void* gdelta, float* dgamma1_a, float* dgamma2_a, float* dgamma1_b, float* dgamma2_b,
+                         float* ws, int accumulate, void* stream);
+
 /* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j]; erf GELU, Phi to 1.5e-7 - */
 int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream);
 int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream);

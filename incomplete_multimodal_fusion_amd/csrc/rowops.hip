@@ -297,6 +297,173 @@ static int add_ln_bwd_nc(const AddLnBwd& p, int nblk, bool hasb, hipStream_t st)
     return MMAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------ dual double-LayerNorm
+// The modality rows of a layer are normalised twice from the same residual value: once with Block_Fusion's (norm1,
+// attn.norm) for the modality attention's K/V and once with Block's (norm1, attn.norm) for the Zorro attention
+// (multimae_crossattn.py:454-470 with DSI-MM/zorro_utils.py:238, :255).  Both first LayerNorms share mean/rstd; one pass
+// reads x (+ delta) once and writes both normalised matrices; the backward takes both upstream gradients and touches
+// x_new / gx_up / gx once (18 B per element instead of 30).  Bias-less (encoder) LayerNorms only.
+struct AddLnFwdDual {
+    const float* x; const void* delta; float* x_new; void* ya; void* yb;
+    const float* g1a; const float* g2a; const float* g1b; const float* g2b;
+    float eps1, eps2; float* stats_a; float* stats_b; long rows; int D;
+};
+template <typename TD, typename TY, int NC>
+__global__ __launch_bounds__(256) void add_ln_fwd_dual_kernel(AddLnFwdDual p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int D = p.D;
+    const float invD = 1.f / (float)D;
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < D) {
+            v[c] = ld4s<float>(p.x + row * D + col);
+            if (p.delta) v[c] += ld4s<TD>(reinterpret_cast<const TD*>(p.delta) + row * D + col);
+            if (p.x_new) st4s<float>(p.x_new + row * D + col, v[c]);
+            s += sum4(v[c]);
+        }
+    }
+    const float m1 = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (col < D) { v[c] = v[c] - m1; q += sum4(v[c] * v[c]); }
+    }
+    const float r1 = rsqrtf(wave_sum(q) * invD + p.eps1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = v[c] * r1;                        // xhat, shared by both paths
+#pragma unroll
+    for (int path = 0; path < 2; ++path) {
+        const float* g1 = path ? p.g1b : p.g1a; const float* g2 = path ? p.g2b : p.g2a;
+        TY* y = reinterpret_cast<TY*>(path ? p.yb : p.ya);
+        f32x4 u[NC];
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            u[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < D) { u[c] = v[c] * ld4f<float>(g1 + col); s2 += sum4(u[c]); }
+        }
+        const float m2 = wave_sum(s2) * invD;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) { const f32x4 d = u[c] - m2; q2 += sum4(d * d); }
+        }
+        const float r2 = rsqrtf(wave_sum(q2) * invD + p.eps2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) st4s<TY>(y + row * D + col, (u[c] - m2) * r2 * ld4f<float>(g2 + col));
+        }
+        if (lane == 0) *reinterpret_cast<f32x4*>((path ? p.stats_b : p.stats_a) + row * 4) = f32x4{m1, r1, m2, r2};
+    }
+}
+
+struct AddLnBwdDual {
+    const float* x_new; const void* gya; const void* gyb; const float* gx_up;
+    const float* g1a; const float* g2a; const float* g1b; const float* g2b;
+    const float* stats_a; const float* stats_b;
+    float* gx; void* gdelta; float* ws;   // ws: (nblk, 4, D) partial column sums [dg1a, dg2a, dg1b, dg2b]
+    long rows; int D;
+};
+template <typename TD, typename TY, int NC>
+__global__ __launch_bounds__(256) void add_ln_bwd_dual_kernel(AddLnBwdDual p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][D] reduction scratch, then g1a, g2a, g1b, g2b [D] each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D;
+    const float invD = 1.f / (float)D;
+    float* sg = red + 4 * D;                                      // sg + (2 * path + k) * D
+    for (int c = threadIdx.x; c < D; c += 256) {
+        sg[c] = p.g1a[c]; sg[D + c] = p.g2a[c]; sg[2 * D + c] = p.g1b[c]; sg[3 * D + c] = p.g2b[c];
+    }
+    __syncthreads();
+    const f32x4 z4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dg[4][NC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dg[k][c] = z4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const f32x4 sta = *reinterpret_cast<const f32x4*>(p.stats_a + row * 4);
+        const f32x4 stb = *reinterpret_cast<const f32x4*>(p.stats_b + row * 4);
+        const float m1 = sta[0], r1 = sta[1];
+        f32x4 xh[NC], tot[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            xh[c] = z4; tot[c] = z4;
+            if (col < D) xh[c] = (ld4s<float>(p.x_new + row * D + col) - m1) * r1;
+        }
+#pragma unroll
+        for (int path = 0; path < 2; ++path) {
+            const float m2 = path ? stb[2] : sta[2], r2 = path ? stb[3] : sta[3];
+            const float* G1 = sg + 2 * path * D; const float* G2 = G1 + D;
+            const TY* gyp = reinterpret_cast<const TY*>(path ? p.gyb : p.gya);
+            f32x4 gv[NC];
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = 4 * (lane + 64 * c);
+                gv[c] = z4;
+                if (col < D) {
+                    const f32x4 gy = ld4s<TY>(gyp + row * D + col);
+                    const f32x4 uh = (xh[c] * *reinterpret_cast<const f32x4*>(G1 + col) - m2) * r2;
+                    dg[2 * path + 1][c] += gy * uh;
+                    const f32x4 guh = gy * *reinterpret_cast<const f32x4*>(G2 + col);
+                    gv[c] = guh;
+                    a += sum4(guh); bsum += sum4(guh * uh);
+                }
+            }
+            const float c1 = wave_sum(a) * invD, c2 = wave_sum(bsum) * invD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = 4 * (lane + 64 * c);
+                if (col < D) {
+                    const f32x4 g1v = *reinterpret_cast<const f32x4*>(G1 + col);
+                    const f32x4 uh = (xh[c] * g1v - m2) * r2;
+                    const f32x4 gu = (gv[c] - c1 - uh * c2) * r2;             // grad wrt u = xhat * g1
+                    dg[2 * path][c] += gu * xh[c];
+                    tot[c] += gu * g1v;                                        // grad wrt xhat, both paths summed
+                }
+            }
+        }
+        float a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { a3 += sum4(tot[c]); a4 += sum4(tot[c] * xh[c]); }
+        const float c3 = wave_sum(a3) * invD, c4 = wave_sum(a4) * invD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) {
+                f32x4 gx = (tot[c] - c3 - xh[c] * c4) * r1;
+                if (p.gx_up) gx += ld4s<float>(p.gx_up + row * D + col);
+                if (p.gx) st4s<float>(p.gx + row * D + col, gx);
+                if (p.gdelta) st4s<TD>(reinterpret_cast<TD*>(p.gdelta) + row * D + col, gx);
+            }
+        }
+    }
+#pragma unroll
+    for (int qn = 0; qn < 4; ++qn) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = 4 * (lane + 64 * c);
+            if (col < D) *reinterpret_cast<f32x4*>(red + wave * D + col) = dg[qn][c];
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += 256)
+            p.ws[((long)blockIdx.x * 4 + qn) * D + col] = red[col] + red[D + col] + red[2 * D + col] + red[3 * D + col];
+    }
+}
+
 #define DISPATCH_TD_TY(FN, ...)                                                                         \
     (dtype_delta == MMAE_BF16                                                                           \
          ? (dtype_y == MMAE_BF16 ? (dbl ? FN<bf16, bf16, true>(__VA_ARGS__) : FN<bf16, bf16, false>(__VA_ARGS__))    \
@@ -339,6 +506,64 @@ extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, c
     if (rc) return rc;
     MMAE_LAUNCH(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
                        dgamma1, dbeta1, dgamma2, dbeta2, accumulate);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_add_ln_fwd_dual(int dtype_delta, int dtype_y, long rows, int D, const float* x, const void* delta,
+                                    float* x_new, void* y_a, void* y_b, const float* gamma1_a, const float* gamma2_a,
+                                    const float* gamma1_b, const float* gamma2_b, float eps1, float eps2, float* stats_a,
+                                    float* stats_b, void* stream) {
+    if (!ok_dtype(dtype_delta) || !ok_dtype(dtype_y) || rows < 0 || D <= 0 || (D % 4) || D > 1024) return MMAE_ERR_ARG;
+    if (!x || !y_a || !y_b || !gamma1_a || !gamma2_a || !gamma1_b || !gamma2_b || !stats_a || !stats_b) return MMAE_ERR_ARG;
+    if (delta && !x_new) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AddLnFwdDual p{x, delta, delta ? x_new : nullptr, y_a, y_b, gamma1_a, gamma2_a, gamma1_b, gamma2_b, eps1, eps2, stats_a, stats_b, rows, D};
+    dim3 grid(cdiv(rows, 4)), blk(256);
+    const int nc = cdiv(D, 256);
+#define GO(TD, TY)                                                                                    \
+    switch (nc) {                                                                                     \
+        case 1: MMAE_LAUNCH((add_ln_fwd_dual_kernel<TD, TY, 1>), grid, blk, 0, st, p); break;         \
+        case 2: MMAE_LAUNCH((add_ln_fwd_dual_kernel<TD, TY, 2>), grid, blk, 0, st, p); break;         \
+        case 3: MMAE_LAUNCH((add_ln_fwd_dual_kernel<TD, TY, 3>), grid, blk, 0, st, p); break;         \
+        default: MMAE_LAUNCH((add_ln_fwd_dual_kernel<TD, TY, 4>), grid, blk, 0, st, p); break;        \
+    }
+    if (dtype_delta == MMAE_BF16) { if (dtype_y == MMAE_BF16) { GO(bf16, bf16) } else { GO(bf16, float) } }
+    else { if (dtype_y == MMAE_BF16) { GO(float, bf16) } else { GO(float, float) } }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_add_ln_bwd_dual(int dtype_delta, int dtype_y, long rows, int D, const float* x_new, const void* gy_a,
+                                    const void* gy_b, const float* gx_up, const float* gamma1_a, const float* gamma2_a,
+                                    const float* gamma1_b, const float* gamma2_b, const float* stats_a, const float* stats_b,
+                                    float* gx, void* gdelta, float* dgamma1_a, float* dgamma2_a, float* dgamma1_b,
+                                    float* dgamma2_b, float* ws, int accumulate, void* stream) {
+    if (!ok_dtype(dtype_delta) || !ok_dtype(dtype_y) || rows < 0 || D <= 0 || (D % 4) || D > 1024) return MMAE_ERR_ARG;
+    if (!x_new || !gy_a || !gy_b || !gamma1_a || !gamma2_a || !gamma1_b || !gamma2_b || !stats_a || !stats_b || !ws) return MMAE_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // persistent grid = what is resident at once: 168 VGPRs -> 3 waves / SIMD -> 3 blocks / CU x 256 CUs (a 1024-block grid
+    // would run as 768 + 256: two rounds)
+    long nblk = (rows + 3) / 4; if (nblk > 768) nblk = 768; if (nblk < 1) nblk = 1;
+    AddLnBwdDual p{x_new, gy_a, gy_b, gx_up, gamma1_a, gamma2_a, gamma1_b, gamma2_b, stats_a, stats_b, gx, gdelta, ws, rows, D};
+    dim3 grid((unsigned)nblk), blk(256);
+    const size_t lds = (size_t)8 * D * sizeof(float);
+    const int nc = cdiv(D, 256);
+#define GO(TD, TY)                                                                                      \
+    switch (nc) {                                                                                       \
+        case 1: MMAE_LAUNCH((add_ln_bwd_dual_kernel<TD, TY, 1>), grid, blk, lds, st, p); break;         \
+        case 2: MMAE_LAUNCH((add_ln_bwd_dual_kernel<TD, TY, 2>), grid, blk, lds, st, p); break;         \
+        case 3: MMAE_LAUNCH((add_ln_bwd_dual_kernel<TD, TY, 3>), grid, blk, lds, st, p); break;         \
+        default: MMAE_LAUNCH((add_ln_bwd_dual_kernel<TD, TY, 4>), grid, blk, lds, st, p); break;        \
+    }
+    if (dtype_delta == MMAE_BF16) { if (dtype_y == MMAE_BF16) { GO(bf16, bf16) } else { GO(bf16, float) } }
+    else { if (dtype_y == MMAE_BF16) { GO(float, bf16) } else { GO(float, float) } }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    MMAE_LAUNCH(colsum_finalize_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, st, ws, (int)nblk, D,
+                dgamma1_a, dgamma2_a, dgamma1_b, dgamma2_b, accumulate);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

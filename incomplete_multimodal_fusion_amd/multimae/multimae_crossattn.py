@@ -16,6 +16,7 @@ Exact algebraic shortcuts relative to the reference (rows are independent, resul
   * the (B,P,M+1,D) `all_tokens` tensor (:454-462) and the (B,h,S,S) score tensor are never materialised.
 """
 import itertools
+import os
 import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple, Union
@@ -101,6 +102,7 @@ class MultiMAE(nn.Module):
         self.attn_pool = Attention(dim=dim_tokens, dim_head=dim_head, heads=heads)
         self.fusion_tokens = nn.Parameter(trunc_normal_(torch.zeros(1, num_fusion_tokens, dim_tokens), std=0.02))
         self.has_fusion_blocks, self.has_contrastive_tokens = bool(fusion_blocks), bool(contrastive_tokens)
+        self.dual_layernorm = os.environ.get("MMAE_DUAL_LN", "1") != "0"   # one pass for the modality rows' two LayerNorm pairs
         if contrastive_tokens:
             for d in self.domains:                                            # return_token_s1 / _s2 / _dem (:105-109)
                 setattr(self, 'return_token_' + d, nn.Parameter(torch.randn(1, 1, dim_tokens)))
@@ -273,20 +275,34 @@ class MultiMAE(nn.Module):
                 fus = self.fus_blocks[l]
                 # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) -----------------------
                 dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
-                (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
-                                                  fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
+                # the modality rows do not change until the Block's attention: both of their double LayerNorms -- this
+                # stage's and the Block's (zorro_utils.py:238) -- come out of ONE pass over the residual (ops dual mode);
+                # zb is the Block's attention input, its fusion rows are filled after the fusion feed-forward below
+                if self.dual_layernorm:
+                    zb = torch.empty(BN + BP, D, dtype=T, device=xm.device)
+                    (xm, xf, _), z, zb = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
+                                                          fus.attn.norm.gamma, None, out_dtype=T,
+                                                          dual=(0, blk.norm1.gamma, blk.attn.norm.gamma, zb, 0))
+                else:                                                                      # two-pass form (A/B, tests)
+                    (xm, xf, _), z = ops.parts_add_ln([xm, xf, me], dl, [o1, o2, -1], fus.norm1.gamma, None,
+                                                      fus.attn.norm.gamma, None, out_dtype=T)       # (BN+BP+P, D)
                 # K/V of every slot source + queries of the fusion slots only, one autograd node (ops._KvQ)
                 kv, q = ops.kv_q_projections(z, BN, BP, fus.attn.to_q.weight, fus.attn.to_kv.weight)
                 a = ops.modattn(q, kv, desc.slot_row, B, P, M + 1, Hh, dh, desc.shared_base, fus.attn.scale)
                 o = linear(a, fus.attn.to_out.weight, side_wgrad=sw, once=True)
                 (xf,), y = ops.parts_add_ln([xf], o, [0], fus.norm2.gamma, None, fus.mlp[0].gamma, None, out_dtype=T)
                 f = ops.feedforward_geglu(y, fus.mlp[1].weight, fus.mlp[3].weight)                    # (BP, D)
-                dl, o1, o2 = f, -1, 0
+                # ---- Block (zorro_utils.py:237-240), Zorro mask as segments ----------------------------------------------
+                if self.dual_layernorm:
+                    (xf,), z = ops.parts_add_ln([xf], f, [0], blk.norm1.gamma, None, blk.attn.norm.gamma, None, out_dtype=T,
+                                                y_into=(zb, BN))                            # (BN+BP, D)
+                else:
+                    (xm, xf), z = ops.parts_add_ln([xm, xf], f, [-1, 0], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
+                                                   out_dtype=T)
             else:                                     # multimae_quadruplet.py:430-432: the Zorro-masked Block only
                 dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
-            # ---- Block (zorro_utils.py:237-240), Zorro mask as segments --------------------------------------------------
-            (xm, xf), z = ops.parts_add_ln([xm, xf], dl, [o1, o2], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
-                                           out_dtype=T)                                     # (BN+BP, D)
+                (xm, xf), z = ops.parts_add_ln([xm, xf], dl, [o1, o2], blk.norm1.gamma, None, blk.attn.norm.gamma, None,
+                                               out_dtype=T)                                 # (BN+BP, D)
             qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
             o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)

@@ -412,24 +412,41 @@ def modattn(q, kv, slot_row, B, P, ns, H, dh, shared_base, scale):
 class _PartsAddLN(torch.autograd.Function):
     """Several row-parts of the fp32 residual stream -> one contiguous normalised matrix.
 
-    forward(delta, g1, b1, g2, b2, cfg, *xs): part i has rows xs[i] (r_i, D) fp32; cfg.delta_off[i] is the row offset
-    of its delta inside `delta` (or -1: no delta, residual unchanged).
-    Returns (x_new_i for the parts that have a delta ..., y) with y = LN2(LN1(x_new)), rows of all parts concatenated.
+    forward(delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf, cfg, *xs): part i has rows xs[i] (r_i, D) fp32;
+    cfg.delta_off[i] is the row offset of its delta inside `delta` (or -1: no delta, residual unchanged).
+    Returns (x_new_i for the parts that have a delta ..., y[, yb]) with y = LN2(LN1(x_new)), rows of all parts concatenated.
+      y_buf / cfg.y_row0: write y into rows [y_row0, y_row0 + total) of an existing matrix instead of a new one (the matrix
+        is returned, marked dirty) -- lets two calls fill one GEMM operand.
+      cfg.dual = (part index, yb_row0) with gb1, gb2, yb_buf: that part is ALSO normalised with the second gamma pair into
+        rows [yb_row0, ...) of yb_buf, in the same pass (mmae_add_ln_fwd_dual / _bwd_dual); bias-less double LayerNorm only.
     """
 
     @staticmethod
-    def forward(ctx, delta, g1, b1, g2, b2, cfg, *xs):
-        eps1, eps2, out_dtype, delta_off = cfg
+    def forward(ctx, delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf, cfg, *xs):
+        eps1, eps2, out_dtype, delta_off, y_row0, dual = cfg
         D = xs[0].shape[1]
         rows = [x.shape[0] for x in xs]
         total = sum(rows)
         dev = xs[0].device
-        y = torch.empty(total, D, dtype=out_dtype, device=dev)
+        if y_buf is None:
+            y = torch.empty(total, D, dtype=out_dtype, device=dev)
+        else:
+            assert y_buf.dtype == out_dtype and y_buf.is_contiguous() and y_buf.shape[1] == D and y_row0 + total <= y_buf.shape[0]
+            y = y_buf
+            ctx.mark_dirty(y_buf)
+        if dual is not None:
+            assert b1 is None and b2 is None and g2 is not None and yb_buf.dtype == out_dtype and yb_buf.is_contiguous()
+            assert dual[1] + rows[dual[0]] <= yb_buf.shape[0] and yb_buf.shape[1] == D
+            ctx.mark_dirty(yb_buf)
+            stats_b = torch.empty(rows[dual[0]], 4, dtype=torch.float32, device=dev)
+        else:
+            stats_b = None
         stats = torch.empty(total, 4, dtype=torch.float32, device=dev)
         ln_in, outs = [], []
         r0 = 0
         ddt = dt(delta) if delta is not None else _lib.F32
-        for x, off in zip(xs, delta_off):
+        esz = y.element_size()
+        for i, (x, off) in enumerate(zip(xs, delta_off)):
             assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == D
             if off >= 0:
                 xn = torch.empty_like(x)
@@ -442,20 +459,29 @@ class _PartsAddLN(torch.autograd.Function):
                     # (added inside the backward kernel) instead of being summed by a separate full-size autograd add
                     outs.append(x.view_as(x))
             if x.shape[0] > 0:                                  # (an empty part -- e.g. no kept token at all -- is legal)
-                call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
-                     ctypes.c_void_p(y.data_ptr() + r0 * D * y.element_size()), ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2),
-                     eps2, ctypes.c_void_p(stats.data_ptr() + r0 * 16), stream())
+                yp = ctypes.c_void_p(y.data_ptr() + (y_row0 + r0) * D * esz)
+                sp = ctypes.c_void_p(stats.data_ptr() + r0 * 16)
+                if dual is not None and i == dual[0]:
+                    call("mmae_add_ln_fwd_dual", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
+                         yp, ctypes.c_void_p(yb_buf.data_ptr() + dual[1] * D * esz), ptr(g1), ptr(g2), ptr(gb1), ptr(gb2),
+                         eps1, eps2, sp, ptr(stats_b), stream())
+                else:
+                    call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
+                         yp, ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2), eps2, sp, stream())
             ln_in.append(xn)
             r0 += x.shape[0]
-        ctx.save_for_backward(g1, b1, g2, stats, *ln_in)
+        ctx.save_for_backward(g1, b1, g2, gb1, gb2, stats, stats_b, *ln_in)
         ctx.meta = (rows, D, delta_off, out_dtype, None if delta is None else (delta.shape, delta.dtype),
-                    b1 is not None, b2 is not None, [off >= 0 or x.requires_grad for x, off in zip(xs, delta_off)])
-        return (*outs, y)
+                    b1 is not None, b2 is not None, [off >= 0 or x.requires_grad for x, off in zip(xs, delta_off)],
+                    y_row0, dual, y_buf is not None)
+        return (*outs, y) if dual is None else (*outs, y, yb_buf)
 
     @staticmethod
     def backward(ctx, *grads):
-        g1, b1, g2, stats, *ln_in = ctx.saved_tensors
-        rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2, has_out = ctx.meta
+        g1, b1, g2, gb1, gb2, stats, stats_b, *ln_in = ctx.saved_tensors
+        rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2, has_out, y_row0, dual, y_given = ctx.meta
+        grads = list(grads)
+        gyb = _c(grads.pop()) if dual is not None else None
         gy = _c(grads[-1])
         ups = list(grads[:-1])          # upstream grads of the x_new / alias outputs, in part order
         dev = gy.device
@@ -466,18 +492,34 @@ class _PartsAddLN(torch.autograd.Function):
                torch.empty(D, dtype=torch.float32, device=dev) if has_b1 else None,
                torch.empty(D, dtype=torch.float32, device=dev) if dbl else None,
                torch.empty(D, dtype=torch.float32, device=dev) if (dbl and has_b2) else None]
+        accb = [torch.zeros(D, dtype=torch.float32, device=dev), torch.zeros(D, dtype=torch.float32, device=dev)] \
+            if dual is not None else [None, None]
         ws = torch.empty(_lib.lib().mmae_add_ln_bwd_ws_floats(max(rows), D), dtype=torch.float32, device=dev)
         gxs = []
         r0 = 0
         first = True
+        esz = gy.element_size()
         for i, (xn, n, off) in enumerate(zip(ln_in, rows, delta_off)):
             up = ups.pop(0) if has_out[i] else None
-            need_gx = ctx.needs_input_grad[6 + i]
+            need_gx = ctx.needs_input_grad[10 + i]
             if n == 0:
                 gxs.append(None)
                 continue
             gx = torch.empty_like(xn) if need_gx else None
             gd = ctypes.c_void_p(gdelta.data_ptr() + off * D * gdelta.element_size()) if off >= 0 else None
+            gyp = ctypes.c_void_p(gy.data_ptr() + (y_row0 + r0) * D * esz)
+            sp = ctypes.c_void_p(stats.data_ptr() + r0 * 16)
+            if dual is not None and i == dual[0]:
+                # accumulate flag: acc[0] / acc[2] follow `first` like every part; the second pair's sums start at zero, so
+                # assigning (first) and adding (not first) are the same thing for them
+                call("mmae_add_ln_bwd_dual", ddt, dt(out_dtype), n, D, ptr(xn), gyp,
+                     ctypes.c_void_p(gyb.data_ptr() + dual[1] * D * esz), ptr(_c(up)) if up is not None else None,
+                     ptr(g1), ptr(g2), ptr(gb1), ptr(gb2), sp, ptr(stats_b), ptr(gx), gd, ptr(acc[0]), ptr(acc[2]),
+                     ptr(accb[0]), ptr(accb[1]), ptr(ws), 0 if first else 1, stream())
+                first = False
+                gxs.append(gx)
+                r0 += n
+                continue
             tm = _TIMERS.get("mmae_add_ln_bwd")
             if tm is not None and not (dbl and not has_b1 and out_dtype == torch.bfloat16 and D == 768 and ddt == _lib.BF16):
                 tm = None       # time one template instance only: <bf16, bf16, 3, double, no beta> (the encoder's)
@@ -488,9 +530,8 @@ class _PartsAddLN(torch.autograd.Function):
                 tm.add_flops(float(n) * D * per)
                 ev0, ev1 = tm.bracket()
                 ev0.record()
-            call("mmae_add_ln_bwd", ddt, dt(out_dtype), n, D, ptr(xn),
-                 ctypes.c_void_p(gy.data_ptr() + r0 * D * gy.element_size()), ptr(_c(up)) if up is not None else None,
-                 ptr(g1), ptr(b1), ptr(g2), ctypes.c_void_p(stats.data_ptr() + r0 * 16), ptr(gx), gd, ptr(acc[0]),
+            call("mmae_add_ln_bwd", ddt, dt(out_dtype), n, D, ptr(xn), gyp, ptr(_c(up)) if up is not None else None,
+                 ptr(g1), ptr(b1), ptr(g2), sp, ptr(gx), gd, ptr(acc[0]),
                  ptr(acc[1]), ptr(acc[2]), ptr(acc[3]), ptr(ws), 0 if first else 1, stream())
             if tm is not None:
                 ev1.record()
@@ -499,16 +540,23 @@ class _PartsAddLN(torch.autograd.Function):
             r0 += n
         if first:
             acc = [None if a is None else torch.zeros_like(a) for a in acc]
-        return (gdelta, acc[0], acc[1], acc[2], acc[3], None, *gxs)
+        return (gdelta, acc[0], acc[1], acc[2], acc[3], accb[0], accb[1], gy if y_given else None, None, None, *gxs)
 
 
 def parts_add_ln(xs: List[torch.Tensor], delta: Optional[torch.Tensor], delta_off: List[int], g1, b1=None, g2=None,
-                 b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32):
-    """-> (list of updated residual parts, y).  A part with delta_off < 0 keeps its residual unchanged."""
-    outs = list(_PartsAddLN.apply(delta, g1, b1, g2, b2, (eps1, eps2, out_dtype, tuple(delta_off)), *xs))
+                 b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32, y_into=None, dual=None):
+    """-> (list of updated residual parts, y).  A part with delta_off < 0 keeps its residual unchanged.
+    y_into = (matrix, row0): y is written into rows [row0, ...) of `matrix` (returned in its place).
+    dual = (part index, gamma1_b, gamma2_b, matrix_b, row0_b): that part is also normalised with the second gamma pair into
+    `matrix_b` in the same pass; the call then returns (parts, y, matrix_b)."""
+    y_buf, y_row0 = (None, 0) if y_into is None else y_into
+    gb1, gb2, yb_buf, dcfg = (None, None, None, None) if dual is None else (dual[1], dual[2], dual[3], (dual[0], dual[4]))
+    outs = list(_PartsAddLN.apply(delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf,
+                                  (eps1, eps2, out_dtype, tuple(delta_off), y_row0, dcfg), *xs))
+    yb = outs.pop() if dual is not None else None
     y = outs.pop()
     x_news = [outs.pop(0) if (off >= 0 or x.requires_grad) else x for x, off in zip(xs, delta_off)]
-    return x_news, y
+    return (x_news, y) if dual is None else (x_news, y, yb)
 
 
 def layernorm(x2d: torch.Tensor, g1, b1=None, g2=None, b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32):

@@ -459,3 +459,41 @@ def test_colsum_bias_gradient_kernel():
     g = torch.randn(4096, 256, device=DEV, dtype=torch.bfloat16)
     ops.linear(xin, w, b).backward(g)
     close(b.grad, g.double().sum(0), 2e-5, "bias grad")
+
+
+@pytest.mark.parametrize("D,T", [(768, torch.bfloat16), (768, torch.float32), (1024, torch.bfloat16), (192, torch.float32)])
+def test_dual_double_layernorm_equals_two_passes(D, T):
+    """parts_add_ln(dual=...) + parts_add_ln(y_into=...) -- the modality rows normalised with two gamma pairs in ONE pass, the
+    second matrix completed by a later call -- against the two-pass composition it replaces: same outputs, same gradients for the
+    residual parts, the delta and all four gammas."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(D)
+    n0, n1, n2 = 333, 150, 16
+    mk = lambda *s: torch.randn(*s, device=DEV)
+    x0, x1, x2 = mk(n0, D), mk(n1, D), mk(n2, D)
+    delta = mk(n0 + n1, D).to(T)
+    f = mk(n1, D).to(T)
+    ga = [torch.rand(D, device=DEV) + 0.5 for _ in range(2)]
+    gb = [torch.rand(D, device=DEV) + 0.5 for _ in range(2)]
+    w_z, w_zb = mk(n0 + n1 + n2, D), mk(n0 + n1, D)
+    w0, w1 = mk(n0, D), mk(n1, D)
+
+    def run(dual):
+        leaves = [t.clone().requires_grad_() for t in (x0, x1, x2, delta, f, *ga, *gb)]
+        a0, a1, a2, dl, ff, ga1, ga2, gb1, gb2 = leaves
+        if dual:
+            zb = torch.empty(n0 + n1, D, dtype=T, device=DEV)
+            (y0, y1, _), z, zb = ops.parts_add_ln([a0, a1, a2], dl, [0, n0, -1], ga1, None, ga2, None, out_dtype=T,
+                                                  dual=(0, gb1, gb2, zb, 0))
+            (y1b,), zb = ops.parts_add_ln([y1], ff, [0], gb1, None, gb2, None, out_dtype=T, y_into=(zb, n0))
+        else:
+            (y0, y1, _), z = ops.parts_add_ln([a0, a1, a2], dl, [0, n0, -1], ga1, None, ga2, None, out_dtype=T)
+            (y0, y1b), zb = ops.parts_add_ln([y0, y1], ff, [-1, 0], gb1, None, gb2, None, out_dtype=T)
+        loss = (z.float() * w_z).sum() + (zb.float() * w_zb).sum() + (y0 * w0).sum() + (y1b * w1).sum()
+        loss.backward()
+        return [z, zb, y0, y1b] + [t.grad for t in leaves]
+    got, ref = run(True), run(False)
+    names = ["z", "zb", "x0_new", "x1_new", "dx0", "dx1", "dx2", "ddelta", "df", "dga1", "dga2", "dgb1", "dgb2"]
+    tol = 2e-2 if T == torch.bfloat16 else 2e-5          # bf16: the two compositions round gdelta / outputs at the same places
+    for n, a, b in zip(names, got, ref):
+        close(a, b, 1e-6 if n in ("z", "zb", "x0_new", "x1_new") else tol, n)
