@@ -82,6 +82,9 @@ class PatchedInputAdapter(_GridAdapter):
         """(B, C, H, W) fp32 image whose kept patches are gathered into the shared embedding GEMM."""
         return x
 
+    def packed_bias(self) -> torch.Tensor:
+        return self.proj.bias
+
     def packed_weight(self) -> torch.Tensor:
         """(D, C*ph*pw) conv weight in (c ph pw) column order."""
         return self.proj.weight.reshape(self.dim_tokens, -1)
@@ -123,11 +126,8 @@ class SemSegInputAdapter(_GridAdapter):
                  dim_tokens: Optional[int] = None, sincos_pos_emb: bool = True, learnable_pos_emb: bool = False,
                  image_size: Union[int, Tuple[int]] = 224, dim_class_emb: int = 64, interpolate_class_emb: bool = False,
                  emb_padding_idx: int = None):
-        if interpolate_class_emb:
-            raise NotImplementedError("interpolate_class_emb=True (bilinear pooling of class embeddings) is not built; the "
-                                      "reference driver passes False (pretrain_mmae_my.py:70-71)")
         self.num_classes = num_classes + (1 if emb_padding_idx is not None else 0)
-        self.dim_class_emb, self.interpolate_class_emb, self.emb_padding_idx = dim_class_emb, False, emb_padding_idx
+        self.dim_class_emb, self.interpolate_class_emb, self.emb_padding_idx = dim_class_emb, bool(interpolate_class_emb), emb_padding_idx
         super().__init__(self.num_classes, stride_level, patch_size_full, dim_tokens, sincos_pos_emb, learnable_pos_emb,
                          image_size)
 
@@ -135,7 +135,31 @@ class SemSegInputAdapter(_GridAdapter):
         super().init(dim_tokens)
         self.class_emb = nn.Embedding(self.num_classes, self.dim_class_emb, padding_idx=self.emb_padding_idx)
         trunc_normal_(self.class_emb.weight, std=0.02)
-        self.proj = nn.Conv2d(self.dim_class_emb, dim_tokens, kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
+        if self.interpolate_class_emb:
+            # reference :288-294: bilinear down-sampling of the embedding map by the patch size, then a 1x1 convolution.
+            # Modules kept as the parameter container (state-dict keys proj.1.weight / proj.1.bias); the arithmetic is the
+            # composed patch weight below: with align_corners=False the sample point of patch row i is 16 i + 7.5, i.e. the
+            # mean of the two centre pixels per axis (one centre pixel for an odd patch size).
+            self.proj = nn.Sequential(nn.Upsample(scale_factor=(1 / self.P_H, 1 / self.P_W), mode='bilinear'),
+                                      nn.Conv2d(self.dim_class_emb, dim_tokens, kernel_size=1, stride=1))
+        else:
+            self.proj = nn.Conv2d(self.dim_class_emb, dim_tokens, kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
+
+    @property
+    def _conv(self) -> nn.Conv2d:
+        return self.proj[1] if self.interpolate_class_emb else self.proj
+
+    def packed_bias(self) -> torch.Tensor:
+        return self._conv.bias
+
+    @staticmethod
+    def _centre_taps(p: int) -> torch.Tensor:
+        k = torch.zeros(p)
+        if p % 2:
+            k[(p - 1) // 2] = 1.0
+        else:
+            k[p // 2 - 1] = k[p // 2] = 0.5
+        return k
 
     @torch.jit.ignore
     def no_weight_decay(self):
@@ -150,17 +174,26 @@ class SemSegInputAdapter(_GridAdapter):
         return F.one_hot(x.long(), self.num_classes).permute(0, 3, 1, 2).to(torch.float32).contiguous()
 
     def packed_weight(self) -> torch.Tensor:
-        w = torch.einsum('dcij,kc->dkij', self.proj.weight.float(), self.class_emb.weight.float())
+        emb = self.class_emb.weight.float()
+        if self.emb_padding_idx is not None:              # nn.Embedding(padding_idx): that row receives no gradient
+            keep = torch.ones(self.num_classes, 1, device=emb.device)
+            keep[self.emb_padding_idx] = 0.0
+            emb = emb * keep + (emb * (1.0 - keep)).detach()
+        cw = self._conv.weight.float()
+        if self.interpolate_class_emb:
+            taps = torch.outer(self._centre_taps(self.P_H), self._centre_taps(self.P_W)).to(cw.device)
+            cw = cw * taps                                 # (D, C, 1, 1) x (P_H, P_W) -> (D, C, P_H, P_W)
+        w = torch.einsum('dcij,kc->dkij', cw, emb)
         return w.reshape(self.dim_tokens, -1)
 
     def forward(self, x):
         B, H, W = x.shape
         nh, nw = self._grid(H, W)
         assert self.P_H == self.P_W
-        T = compute_dtype(self.proj.weight)
+        T = compute_dtype(self._conv.weight)
         K = self.num_classes * self.P_H * self.P_W
         patches = ops.patchify_gather([self.packed_image(x)], [0], -1, K, self.P_H, None, None, nh * nw, T)
-        tok = linear(patches, self.packed_weight(), self.proj.bias)
+        tok = linear(patches, self.packed_weight(), self._conv.bias)
         pe = self.pos_emb
         if pe.shape[-2:] != (nh, nw):
             pe = F.interpolate(pe, size=(nh, nw), mode='bilinear')                 # reference :322 (bilinear here)

@@ -244,7 +244,7 @@ class MultiMAE(nn.Module):
         pcat = ops.patchify_gather([self.input_adapters[d].packed_image(x[d]) for d in doms], koff, onehot, Kcat, ps,
                                    desc.tok_mod, desc.tok_patch, N, T)
         wcat = torch.cat([self.input_adapters[d].packed_weight() for d in doms] +
-                         [torch.stack([self.input_adapters[d].proj.bias for d in doms], dim=1),
+                         [torch.stack([self.input_adapters[d].packed_bias() for d in doms], dim=1),
                           pcat.new_zeros(D, Kcat - onehot - M, dtype=torch.float32)], dim=1)
         tok = linear(pcat, wcat, once=True)                                                   # (B*N, D), bias included
         pe_table = torch.cat([interp_posemb(self.input_adapters[d].pos_emb, nh, nw) for d in doms], dim=0)

@@ -494,6 +494,18 @@ def gen_aux():
             dem_mean=d.dem_MEAN, dem_std=d.dem_STD, rgb_in=rgb, rgb_out=d.normalize_rgb(rgb.copy()),
             sar_in=sar, sar_out=d.normalize_sar(sar.copy()), dem_in=dem, dem_out=d.normalize_dem(dem.copy()),
             minmax_out=d.normalization(dem.copy()))
+    # (appended last so that the draws of the cases above are unchanged) the SemSeg adapter with interpolate_class_emb=True (:288-294) and an embedding padding index (zero-gradient row)
+    torch.manual_seed(5002)
+    ssi = aux.ia.SemSegInputAdapter(num_classes=5, stride_level=1, patch_size_full=8, dim_tokens=32, image_size=32,
+                                    dim_class_emb=8, interpolate_class_emb=True, emb_padding_idx=5)
+    rand_init_(ssi, gen)
+    xi = torch.randint(0, 6, (2, 32, 32), generator=gen)
+    gi = R(2, 16, 32)
+    yi = ssi(xi)
+    gsi = grads_of(yi, gi, [ssi.class_emb.weight, ssi.proj[1].weight, ssi.proj[1].bias])
+    bag.put("semseg_input_interp", x=xi, y=yi, g=gi, gclass_emb=gsi[0], gweight=gsi[1], gbias=gsi[2],
+            **{"w." + k: v for k, v in ssi.state_dict().items()})
+
     np.savez_compressed(os.path.join(OUT, "aux.npz"), **bag)
     print("aux.npz:", len(bag), "arrays")
 
