@@ -461,14 +461,15 @@ def test_colsum_bias_gradient_kernel():
     close(b.grad, g.double().sum(0), 2e-5, "bias grad")
 
 
-@pytest.mark.parametrize("D,T", [(768, torch.bfloat16), (768, torch.float32), (1024, torch.bfloat16), (192, torch.float32)])
-def test_dual_double_layernorm_equals_two_passes(D, T):
+@pytest.mark.parametrize("D,T,n0", [(768, torch.bfloat16, 333), (768, torch.float32, 333), (1024, torch.bfloat16, 333),
+                                    (192, torch.float32, 333), (768, torch.bfloat16, 0), (768, torch.bfloat16, 5000)])
+def test_dual_double_layernorm_equals_two_passes(D, T, n0):
     """parts_add_ln(dual=...) + parts_add_ln(y_into=...) -- the modality rows normalised with two gamma pairs in ONE pass, the
     second matrix completed by a later call -- against the two-pass composition it replaces: same outputs, same gradients for the
     residual parts, the delta and all four gammas."""
     from incomplete_multimodal_fusion_amd import ops
     torch.manual_seed(D)
-    n0, n1, n2 = 333, 150, 16
+    n1, n2 = 150, 16                       # n0 = 0: no kept modality token at all; 5000: more rows than the persistent grid
     mk = lambda *s: torch.randn(*s, device=DEV)
     x0, x1, x2 = mk(n0, D), mk(n1, D), mk(n2, D)
     delta = mk(n0 + n1, D).to(T)
@@ -496,4 +497,7 @@ def test_dual_double_layernorm_equals_two_passes(D, T):
     names = ["z", "zb", "x0_new", "x1_new", "dx0", "dx1", "dx2", "ddelta", "df", "dga1", "dga2", "dgb1", "dgb2"]
     tol = 2e-2 if T == torch.bfloat16 else 2e-5          # bf16: the two compositions round gdelta / outputs at the same places
     for n, a, b in zip(names, got, ref):
+        if a is None or b is None:                       # an empty part has no gradient in either composition
+            assert a is None and b is None, n
+            continue
         close(a, b, 1e-6 if n in ("z", "zb", "x0_new", "x1_new") else tol, n)
