@@ -189,6 +189,23 @@ class GradAllReducer:
                         self._unused.add(p)
             self._launch(b)
         self._next = len(self.buckets)
+        if self._first and self.static_unused and self.world > 1:
+            # the static set must be the SAME on every rank: agree once.  A parameter without a gradient on every rank is
+            # excluded for good; if the ranks disagree on any parameter (per-rank modality subsets, ...), a static set
+            # would let replicas drift apart (one rank updates the parameter, another does not): switch to the
+            # per-step agreement of static_unused=False.
+            loc = torch.tensor([[0, 1] if p.grad is None else [1, 0] for p in self.params], dtype=torch.int32,
+                               device=self.buckets[0].flat.device)
+            dist.all_reduce(loc, op=dist.ReduceOp.MAX, group=self.group)
+            any_used, any_unused = loc[:, 0].tolist(), loc[:, 1].tolist()
+            if any(u and n for u, n in zip(any_used, any_unused)):
+                import warnings
+                warnings.warn("GradAllReducer: ranks disagree on the set of parameters that received a gradient on the "
+                              "first step; switching to static_unused=False (per-step agreement)")
+                self.static_unused = False
+                self._unused = set()
+            else:
+                self._unused = {p for p, u in zip(self.params, any_used) if not u}
         used = None
         if not self.static_unused and self.world > 1:
             flags = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,

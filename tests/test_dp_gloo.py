@@ -178,3 +178,41 @@ def test_static_unused_raises_when_an_excluded_parameter_gets_a_gradient():
     out = _run_dynamic(static=True)
     errs = [err for _, _, err in out]
     assert any(e and "static_unused=False" in e for e in errs), errs
+
+
+# first step: rank 1 uses the side branch, rank 0 does not -> a per-rank static set would let the replicas drift apart
+_SIDE_MIXED = {(0, 0): False, (0, 1): True, (1, 0): True, (1, 1): False, (2, 0): True, (2, 1): True}
+
+
+@pytest.mark.timeout(120)
+def test_static_unused_switches_to_per_step_agreement_when_ranks_disagree_on_the_first_step():
+    global _SIDE
+    saved = dict(_SIDE)
+    try:
+        _SIDE.clear(); _SIDE.update(_SIDE_MIXED)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_mixed, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=30)
+    finally:
+        _SIDE.clear(); _SIDE.update(saved)
+    (r0, res0, err0), (r1, res1, err1) = out
+    assert err0 is None and err1 is None, (err0, err1)
+    for step in range(3):
+        for n in res0[step]:
+            assert res0[step][n] is not None and res1[step][n] is not None, (step, n)     # used somewhere -> present everywhere
+            assert torch.allclose(torch.tensor(res0[step][n]), torch.tensor(res1[step][n]), atol=1e-7), (step, n)
+
+
+def _worker_mixed(rank, world, port, q):
+    global _SIDE
+    _SIDE.clear(); _SIDE.update(_SIDE_MIXED)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _worker_dynamic(rank, world, port, q, True)
