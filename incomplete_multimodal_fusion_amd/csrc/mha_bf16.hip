@@ -955,6 +955,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 // `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
+    if (head_dim == 64 && g_variant >= 5 && g_variant <= 8) return mha_sh_fwd(d, g_variant - 5, st);   // sample-head forward (mha_sh.hip); 6 / 7 / 8: diagnostics
     if (head_dim == 64 && (g_variant == 0 || g_variant == 3 || g_variant == 4 || g_variant == 9)) {
         // default (0 == 3): 32x32x16 forward, 4 waves x 32 queries = 128-query tiles; 4: 256-query tiles; 9: stamped diagnostic
         MhaDesc e = d;
@@ -966,7 +967,7 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
     } else if (head_dim == 64 && g_variant == 2) {           // round-1 kernel: 16x16x32, 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 4, 2>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(256), 0, st, e);
-    } else if (head_dim == 64 && g_variant == 8) {           // 8 waves x 16 queries (measured: no gain over 4 x 16)
+    } else if (head_dim == 64 && g_variant == 18) {          // 8 waves x 16 queries (measured: no gain over 4 x 16)
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_fwd_kernel<64, 8>), dim3(xcd_grid(e.B, e.H, e.max_tiles)), dim3(512), 0, st, e);
     } else {                                                 // variant 1 (dh 64) / dh 32: 16x16x32, 4 waves x 16 queries

@@ -53,3 +53,5 @@ __device__ __forceinline__ TileSel select_tile(const int* len, int nseg, int t) 
 // bf16 fast path (mha_bf16.hip)
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int variant, hipStream_t st);
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int variant, hipStream_t st);
+// sample-head kernels (mha_sh.hip): bf16, head_dim 64; d.max_tiles = key tiles per sample (upper bound)
+int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st);   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics

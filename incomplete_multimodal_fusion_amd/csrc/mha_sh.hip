@@ -1,0 +1,523 @@
+// "Sample-head" kernels of the segment-masked attention, bf16, head_dim 64 (gfx950).  Semantics: mha.hip's header.
+//
+// What bounds the tile-per-block kernels of mha_bf16.hip at the pretraining shapes (S = 640 rows per sample, 8 heads x 64)
+// is not the matrix core but start-up latency: a block lives for ~5 key tiles and spends 43 % of that waiting for its
+// segment table, its Q rows and its first K/V tile (profiles/r02_attention.md), and every K/V tile is staged once per
+// 128-query tile.  The whole forward moves 671 MB for 112 GFLOP -- at the chip's ridge it is an HBM-streaming problem.
+// Here the Zorro mask's structure does the work instead:
+//   * ONE workgroup (8 waves, one per CU) owns a sample and walks its heads; per (sample, head) every K/V tile is fetched
+//     and staged exactly ONCE and serves both kinds of query that may see it -- the fusion queries (they see every key:
+//     "global" slot of a wave, 32 queries) and the queries of the tile's own modality ("local" slot, 32 queries);
+//   * K/V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, no VGPRs) into a 4-stage ring, issued
+//     three tiles ahead of their use and across head boundaries: the stream never drains between (sample, head) items, one
+//     s_barrier per tile, counted vmcnt waits;
+//   * Q rows are prefetched the same way into a wave-private staging area one segment (local slot) / one pass (global slot)
+//     ahead -- no block barrier, the wave waits for its own DMA -- so a slot switch costs four LDS reads;
+//   * images are plain 128-byte rows (the DMA destination is lane-linear); bank conflicts are removed by a swizzle applied
+//     on the SOURCE side: 16-byte chunk c of row r sits at chunk c ^ f(r), f(r) = r1<<2 | r2<<1 | r3 (bits of r), which makes
+//     both the b128 row reads and the ds_read_b64_tr_b16 transposed reads of the 32x32x16 operands conflict free
+//     (tools/probes/lds_swizzle_check.py);
+//   * the running reference -m and the mask of a ragged tile's padded keys enter the scores through ONE extra k-step
+//     (K side [1, pad ? -1e30 : 0], Q side [-m, 1]): no accumulator splat, no per-element compare; m is kept
+//     bf16-representable so the seed is exact.
+// Segments longer than 256 queries take further passes over the tile list (chunk c = queries [256c, 256c + 256) of every
+// segment); query segments whose key segment is empty attend uniformly (empty_mode 0: extra passes with a zero query on the
+// global slot) or produce zeros (empty_mode 1).
+#include "mha_common.hpp"
+#include "mmae_hip.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define LDS_AS __attribute__((address_space(3)))
+
+#define SH_NS 4                 // ring stages
+#define SH_D 3                  // tiles in flight ahead of the consumer
+#define SH_MAXT 64              // key tiles per sample (one lane each)
+#define SH_MAXP 64              // passes per sample (one lane each)
+#define SH_LOG2E 1.4426950408889634f
+#define SH_LN2 0.6931471805599453f
+#define SH_THR 6.0f             // log2 domain: P <= 2^6 between rescales
+
+__device__ __forceinline__ int sh_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int sh_f(int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1); }
+__device__ __forceinline__ float sh_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ f32x16 sh_mma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sh_swap_max(float v) {
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float sh_swap_sum(float v) {
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+// s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction only takes an immediate): a computed jump into a table of
+// 32 { s_waitcnt vmcnt(k); s_branch end } pairs -- 8 scalar instructions whatever n is (as a C switch hipcc emitted a tree of a
+// dozen compare / branch pairs per call, a few hundred cycles at the top of every tile).  n = how many YOUNGER vector-memory
+// instructions may stay in flight; rounding n down only waits for more, so counts above 31 use 31.
+#define SH_W1(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch .Lshw_end_%=\n\t"
+#define SH_W4(a, b, c, d) SH_W1(a) SH_W1(b) SH_W1(c) SH_W1(d)
+__device__ __forceinline__ void sh_wait_vm(int n) {
+    int k = sh_uni(n < 0 ? 0 : (n > 31 ? 31 : n));
+    asm volatile(
+        "s_getpc_b64 vcc\n\t"                 // address of the next instruction; the table starts 20 bytes further on
+        "s_lshl_b32 %0, %0, 3\n\t"
+        "s_add_u32 %0, %0, 20\n\t"
+        "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+        "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+        "s_setpc_b64 vcc\n\t"
+        SH_W4(0, 1, 2, 3) SH_W4(4, 5, 6, 7) SH_W4(8, 9, 10, 11) SH_W4(12, 13, 14, 15)
+        SH_W4(16, 17, 18, 19) SH_W4(20, 21, 22, 23) SH_W4(24, 25, 26, 27) SH_W4(28, 29, 30, 31)
+        ".Lshw_end_%=:"
+        : "+s"(k) : : "vcc", "scc", "memory");
+}
+__device__ __forceinline__ float sh_bf16_round(float x) { return (float)(bf16)x; }
+__device__ __forceinline__ unsigned sh_pack2(float lo, float hi) {
+    const unsigned a = __builtin_bit_cast(unsigned short, (bf16)lo), b = __builtin_bit_cast(unsigned short, (bf16)hi);
+    return a | (b << 16);
+}
+__device__ __forceinline__ bf16x8 sh_ext(unsigned w0) { return __builtin_bit_cast(bf16x8, u32x4{w0, 0u, 0u, 0u}); }
+
+// segment table of one sample: lane s holds entry s (one parallel round trip); wave-uniform reads through v_readlane
+struct ShSeg {
+    int qlen, qst, klen, kst;
+    __device__ __forceinline__ void load(const MhaDesc& p, int b, int lane) {
+        const int i = b * p.nseg + (lane < p.nseg ? lane : 0);
+        qlen = p.q_len[i]; qst = p.q_start[i]; klen = p.k_len[i]; kst = p.k_start[i];
+    }
+    __device__ __forceinline__ int ql(int s) const { return __builtin_amdgcn_readlane(qlen, sh_uni(s)); }
+    __device__ __forceinline__ int qs(int s) const { return __builtin_amdgcn_readlane(qst, sh_uni(s)); }
+    __device__ __forceinline__ int kl(int s) const { return __builtin_amdgcn_readlane(klen, sh_uni(s)); }
+    __device__ __forceinline__ int ks(int s) const { return __builtin_amdgcn_readlane(kst, sh_uni(s)); }
+};
+
+// one 1-KiB LDS-DMA piece: 8 rows x 128 B of a [rows][row_bytes] matrix; lane l fetches the 16-byte chunk that belongs at
+// byte 16 l of the piece under the swizzle (voff, loop invariant per lane); rows >= n fail the range check
+// The descriptor inputs go through v_readfirstlane: they ARE wave-uniform, but unless that is provable hipcc wraps every
+// buffer instruction in a "waterfall" loop (4 readfirstlane + 2 compares + exec save / restore per DMA: the stamped build showed
+// ~500 cycles per LDS-DMA instruction; cdna_hip_programming.md T20).
+__device__ __forceinline__ void sh_dma(const bf16* base, int n_rows, int row_bytes, int voff, int soff, bf16* lds_piece) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    bf16* ub = reinterpret_cast<bf16*>(((unsigned long long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, sh_uni(n_rows * row_bytes), 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds_piece, 16, voff, sh_uni(soff), 0, 0);
+}
+
+// transposed operand of the 32x32x16 products: element j of lane (r = lane & 31, hh = lane >> 5) is
+// X[base + 8 (j >> 2) + 4 hh + (j & 3)][32 dhb + r] of the swizzled image (mha_bf16.hip: tr32_frag)
+__device__ __forceinline__ bf16x8 sh_tr(const bf16* img, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + off1));
+    s16x8 x;
+    x[0] = lo[0]; x[1] = lo[1]; x[2] = lo[2]; x[3] = lo[3]; x[4] = hi[0]; x[5] = hi[1]; x[6] = hi[2]; x[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, x);
+}
+__device__ __forceinline__ bf16x8 sh_ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// Lane-invariant LDS element offsets of the fragment reads, swizzle folded in.  Only TWO registers: the other offsets differ
+// from these by XOR with a constant (the swizzle is an XOR on address bits 3-5 of a 128-byte row, k-step / dh-block / row-group
+// indices are XORed in the same way), and the kernels XOR them onto an address that already carries the ring stage -- a
+// loop-variant value, so the compiler cannot hoist eight address registers out of the tile loop (at a 128-VGPR budget they
+// were what spilled, and every scratch reload drains the DMA queue with its vmcnt(0)).
+//   row read,  row (lane & 31) of a 32-row block, k-step ks :  krow0 ^ (16 ks)
+//   transposed read, dh block d, row group e (rows +8 e)     :  tr00 ^ (32 d + 520 e)
+struct ShAddr {
+    int krow0, tr00;
+    __device__ __forceinline__ void init(int lane) {
+        const int r = lane & 31, hh = lane >> 5;
+        krow0 = r * 64 + 8 * (hh ^ sh_f(r));
+        const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const int row = 4 * (g16 >> 1) + q, ch = 2 * (g16 & 1) + (pp >> 1);
+        tr00 = row * 64 + 8 * (ch ^ sh_f(row)) + 4 * (pp & 1);
+    }
+};
+
+// a wave's query slot: 32 queries (one per lane pair r / r + 32), online-softmax state in registers
+struct ShSlot {
+    bf16x8 q[4];
+    f32x16 o[2];
+    float mref, lsum;
+    unsigned ext;         // Q side of the seed k-step: (bf16(-mref), 1.0) on lanes < 32, 0 above
+    int row;              // this lane's query row in the q / out matrices
+    int nq;               // valid queries of the slot (wave-uniform): lane pair r is live iff r < nq
+};
+
+// Diagnostic build (MODE 3; never the product path): per-wave s_memtime sums of where an iteration goes.  One row per wave,
+// plain stores; mmae_debug_sh_stamps() sums the rows of the two roles separately and clears them.
+//   [0] vmcnt wait at the top  [1] barrier  [2] ring issue + tile record  [3] slot switch  [4] QK^T  [5] softmax  [6] PV
+//   [7] finish (stores)  [8] whole loop  [9] units (slot-steps)  [10] iterations  [11] waves
+//   slot switch in detail: [12] wait for the staged Q  [13] LDS reads + conversion  [14] next-target scan  (the rest of [3] is the Q DMA issue)
+#define SH_STAMP_WAVES 8192
+__device__ unsigned long long g_sh_stamps[SH_STAMP_WAVES][16];
+__device__ __forceinline__ unsigned long long sh_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+extern "C" int mmae_debug_sh_stamps(unsigned long long* host32) {
+    if (!host32) return MMAE_ERR_ARG;
+    static unsigned long long* h = nullptr;
+    if (!h) h = new unsigned long long[(size_t)SH_STAMP_WAVES * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sh_stamps), sizeof(unsigned long long) * SH_STAMP_WAVES * 16) != hipSuccess) return MMAE_ERR_LAUNCH;
+    for (int i = 0; i < 32; ++i) host32[i] = 0;
+    for (size_t w = 0; w < SH_STAMP_WAVES; ++w)
+        for (int i = 0; i < 16; ++i) host32[16 * ((w & 15) >= 8) + i] += h[w * 16 + i];      // [0..15] global waves, [16..31] local waves
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_sh_stamps)) != hipSuccess) return MMAE_ERR_LAUNCH;
+    if (hipMemset(dptr, 0, sizeof(unsigned long long) * SH_STAMP_WAVES * 16) != hipSuccess) return MMAE_ERR_LAUNCH;
+    return MMAE_OK;
+}
+#define SH_T(i) do { if (ST) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n__ = sh_now(); tt[i] += n__ - tl; tl = n__; __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+// scores of 64 keys x 32 queries, online softmax, O^T += V^T P^T
+template <bool ST>
+__device__ __forceinline__ void sh_attend(ShSlot& s, bool fresh, const bf16* Kst, const bf16* Vst, int stage_el, const ShAddr& ad,
+                                          const unsigned (&kext)[2], int hh, unsigned long long (&tt)[16], unsigned long long& tl) {
+    f32x16 sacc[2];
+    const bf16x8 qe = sh_ext(s.ext);
+    const int kbase = ad.krow0 + stage_el, vbase = ad.tr00 + stage_el;      // element offsets incl. the ring stage (see ShAddr)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        sacc[kb] = sh_mma(sh_ext(kext[kb]), qe, z);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sacc[kb] = sh_mma(sh_ld8(Kst + 2048 * kb + (kbase ^ (16 * ks))), s.q[ks], sacc[kb]);
+    }
+    if (ST) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");    // let the MFMA chain drain into [4]
+    SH_T(4);
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, sacc[0][i]), sacc[1][i]);
+    mx = sh_swap_max(mx);
+    const bool need = fresh | (mx > SH_THR);
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {              // wave-uniform: first tile, or some row outgrew its reference
+        const float want = s.mref + (fresh ? mx : fmaxf(mx, 0.f));
+        const float mnew = sh_bf16_round(want);
+        const float delta = mnew - s.mref;                       // exact: both are bf16 values
+        if (!fresh) {
+            const float alpha = sh_exp2(-delta);
+            s.lsum *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s.o[d][i] *= alpha;
+        }
+        s.mref = mnew;
+        s.ext = hh == 0 ? sh_pack2(-mnew, 1.0f) : 0u;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] -= delta;
+    }
+    // the row sum is taken over the bf16-ROUNDED probabilities (v_dot2c_f32_bf16 with a pair of ones: one instruction per two
+    // keys): O = sum(P_r V) / sum(P_r) is then an exact weighted mean -- a row with a single key returns V itself, which the
+    // backward's dP - delta cancellation relies on -- whatever the (bf16-valued, deferred) reference happens to be
+    bf16x8 pb[2][2];
+    const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[kb][i] = sh_exp2(sacc[kb][i]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[kb][s2][j] = (bf16)sacc[kb][8 * s2 + j];
+            const u32x4 w = __builtin_bit_cast(u32x4, pb[kb][s2]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s.lsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, (unsigned)w[j]), ones, s.lsum, false);
+        }
+    }
+    SH_T(5);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16* vb = Vst + 64 * (32 * kb + 16 * s2);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) s.o[d] = sh_mma(sh_tr(vb, vbase ^ (32 * d), vbase ^ (32 * d + 520)), pb[kb][s2], s.o[d]);
+        }
+        if (kb == 0) __builtin_amdgcn_sched_barrier(0);           // at most 8 transposed fragments in flight (VGPR budget: 128)
+    }
+    if (ST) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    SH_T(6);
+}
+
+// Normalise and store a slot's 32 x 64 output tile.  A lane pair (r, r + 32) holds one query row: lane half hh owns the
+// columns 32 d + 8 i + 4 hh + (0..3) of accumulator register group (d, i).  v_permlane32_swap on neighbouring groups (i, i + 1)
+// gives each lane 16 contiguous bytes (lower half: columns 8 i .. 8 i + 7, upper half: 8 i + 8 .. 8 i + 15), so the tile leaves
+// in 4 dwordx4 stores per lane instead of 8 dwordx2 -- the epilogue of a row-per-lane tile is store-ISSUE bound
+// (cdna_hip_programming.md T21; the stamped build showed 6.6k cycles per finish with the narrow stores).
+__device__ __forceinline__ void sh_finish(const ShSlot& s, const MhaDesc& p, int h, int r, int hh) {
+    const float lq = sh_swap_sum(s.lsum);
+    const float inv = lq > 0.f ? 1.f / lq : 0.f;
+    const bool valid = r < s.nq;
+    bf16* op = reinterpret_cast<bf16*>(p.o) + (long)s.row * p.o_stride + h * 64 + 8 * hh;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            unsigned a0 = sh_pack2(s.o[d][4 * i] * inv, s.o[d][4 * i + 1] * inv), a1 = sh_pack2(s.o[d][4 * i + 2] * inv, s.o[d][4 * i + 3] * inv);
+            unsigned b0 = sh_pack2(s.o[d][4 * i + 4] * inv, s.o[d][4 * i + 5] * inv), b1 = sh_pack2(s.o[d][4 * i + 6] * inv, s.o[d][4 * i + 7] * inv);
+            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+            if (valid) *reinterpret_cast<u32x4*>(op + 32 * d + 8 * i) = u32x4{a0, a1, b0, b1};
+        }
+    if (valid && hh == 0) p.lse[(long)h * p.stat_stride + s.row] = lq > 0.f ? s.mref * SH_LN2 + __logf(lq) : 0.f;
+}
+
+// zero output rows (empty key context under empty_mode 1, or a sample without keys): every thread of the block takes part
+__device__ __forceinline__ void sh_zero_rows(const MhaDesc& p, long row0, int n, int h, int tid) {
+    for (int i = tid; i < n * 8; i += 1024) {
+        const int rr = i >> 3, c = i & 7;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.o) + (row0 + rr) * p.o_stride + h * 64 + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+        if (c == 0) p.lse[(long)h * p.stat_stride + row0 + rr] = 0.f;
+    }
+}
+
+// MODE (diagnostic builds, never the product path): 1 = stream only (no scores), 2 = compute only (no K/V DMA: stale tiles),
+// 3 = stamped (g_sh_stamps)
+//
+// 16 waves, four per SIMD, ONE query slot per wave: waves 0-7 hold the "global" queries of the pass (the fusion chunk, or a
+// fully masked segment's chunk attending uniformly), waves 8-15 the "local" queries of the segment whose key tiles are being
+// swept.  Each SIMD then runs two global and two local waves; with four resident waves the LDS / MFMA latencies of one wave
+// are covered by the others without hand-interleaving (the first version of this kernel -- 8 waves with both slots in every
+// wave, 212 VGPRs, two waves per SIMD running the same code in lock-step -- measured 230-240 us at the bench shape with
+// 41 % of wave cycles parked and 22 % issue-stalled: no faster than the tile-per-block kernel).
+template <int MODE>
+__global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
+    __shared__ __attribute__((aligned(1024))) bf16 ringK[SH_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 ringV[SH_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 qst[16][32 * 64];       // wave-private Q staging: 32 rows x 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = sh_uni(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const bool local = wave >= 8;                                   // role of this wave
+    const int qw = wave & 7;                                        // its 32-query block inside a 256-query chunk
+    const int hgroups = p.H / hpb;
+    const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * hpb;
+    const int nseg = p.nseg, fus = nseg - 1;
+    ShSeg st; st.load(p, b, lane);
+    // Schedule of this sample, held in registers by every wave (lane i = entry i, read with v_readlane: no LDS round trip in the
+    // loop).  Tiles: first key row and n | seg << 8 | (first-of-segment | last-of-segment << 1) << 16.
+    // Passes: (global segment + 1) | global chunk << 8 | (local chunk + 1) << 16.
+    int tile_row = 0, tile_info = 0, pass_info = 0, ntile = 0, npass = 0;
+    {
+        int acc = 0;
+        for (int s = 0; s < nseg; ++s) {
+            const int L = st.kl(s), nt = (L + 63) >> 6, j = lane - acc;
+            if (j >= 0 && j < nt) { tile_row = st.ks(s) + 64 * j; tile_info = min(64, L - 64 * j) | (s << 8) | (((j == 0 ? 1 : 0) | (j == nt - 1 ? 2 : 0)) << 16); }
+            acc += nt;
+        }
+        ntile = min(acc, SH_MAXT);
+        int nch = 1;
+        for (int s = 0; s < nseg; ++s) nch = max(nch, (st.ql(s) + 255) >> 8);
+        if (lane < nch) pass_info = ((256 * lane < st.ql(fus) ? fus : -1) + 1) | (lane << 8) | ((lane + 1) << 16);
+        acc = nch;
+        if (p.empty_mode == 0)                                     // fully masked rows: uniform attention over every key
+            for (int s = 0; s < fus; ++s)
+                if (st.kl(s) == 0 && st.ql(s) > 0) {
+                    const int nc = (st.ql(s) + 255) >> 8, j = lane - acc;
+                    if (j >= 0 && j < nc) pass_info = (s + 1) | (j << 8);
+                    acc += nc;
+                }
+        npass = min(acc, SH_MAXP);
+    }
+    auto t_row = [&](int t) { return __builtin_amdgcn_readlane(tile_row, t); };
+    auto t_info = [&](int t) { return __builtin_amdgcn_readlane(tile_info, t); };
+    auto p_info = [&](int pi) { return __builtin_amdgcn_readlane(pass_info, pi); };
+    // rows that see no key at all
+    for (int hi = 0; hi < hpb; ++hi)
+        for (int s = 0; s < nseg; ++s) {
+            const int QL = st.ql(s);
+            if (QL > 0 && (ntile == 0 || (s < fus && st.kl(s) == 0 && p.empty_mode == 1))) sh_zero_rows(p, st.qs(s), QL, h0 + hi, tid);
+        }
+    if (ntile == 0) return;
+
+    const bf16* qg = reinterpret_cast<const bf16*>(p.q);
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    const int qsb = (int)p.q_stride * 2, kvsb = (int)p.k_stride * 2;          // (host: k_stride == v_stride)
+    // DMA source offsets: lane l of a piece fills bytes [16 l, 16 l + 16) = row l >> 3, chunk position l & 7.
+    // (row 8 j + prow of a block: f(row) = f(prow) ^ (j & 1), so ONE register serves every piece of a matrix: the row part 8 j
+    // goes into the scalar offset, odd pieces flip bit 4)
+    const int prow = lane >> 3;
+    const int kvoff = prow * kvsb + 16 * ((lane & 7) ^ sh_f(prow));
+    const int qvoff = prow * qsb + 16 * ((lane & 7) ^ sh_f(prow));
+    ShAddr ad; ad.init(lane);
+    const float cq = p.scale * SH_LOG2E;
+
+    const int G = hpb * npass * ntile;
+    // vmcnt bookkeeping: `vm` counts every vector-memory instruction this wave has issued (ring DMA, Q staging DMA, stores);
+    // an operation's sequence number is vm right after its issue, and "wait for it" is s_waitcnt vmcnt(vm - seq).
+    int vm = 0;
+    // The ring is filled by ONE wave per tile, all 16 pieces (8 K + 8 V): an LDS-DMA instruction occupies the CU's
+    // address path for ~40 cycles, and with every wave issuing its own piece right behind the barrier each of them sat
+    // 500-800 cycles in that queue per tile (stamped build).  The loader of step j is wave 12 + (j & 3): the local-role waves of
+    // the upper half of a chunk, which hold queries only where a modality keeps more than 128 tokens -- at the usual splits they
+    // are idle, so the ~230 cycles an LDS-DMA instruction costs its issuer (16 per tile) are nobody's critical path.  Only the
+    // loader waits for the step's pieces (vmcnt) before the barrier.
+    int lt = 0, lh = 0, lpt = npass * ntile;                        // tile / head of ring step `lj`, tiles left in that head
+    int lj = 0, lstage = 0, myseq = 0;
+    auto issue_ring = [&]() {                                       // every wave advances the position; the step's loader issues
+        if (MODE != 2 && wave == 12 + (lj & 3)) {
+            const long row0 = t_row(lt); const int n = t_info(lt) & 255;
+            const bf16* kb_ = kg + row0 * p.k_stride + (h0 + lh) * 64;
+            const bf16* vb_ = vg + row0 * p.v_stride + (h0 + lh) * 64;
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                sh_dma(kb_, n, kvsb, kvoff ^ (16 * (pc & 1)), 8 * pc * kvsb, &ringK[lstage][pc * 512]);
+                sh_dma(vb_, n, kvsb, kvoff ^ (16 * (pc & 1)), 8 * pc * kvsb, &ringV[lstage][pc * 512]);
+            }
+            vm += 16; myseq = vm;
+        }
+        ++lj;
+        if (++lstage == SH_NS) lstage = 0;
+        if (++lt == ntile) lt = 0;
+        if (--lpt == 0) { lpt = npass * ntile; ++lh; }
+    };
+    // Q staging: rows [256 chunk + 32 qw, +32) of query segment s, head h -> qst[wave]
+    auto rows_of = [&](int s, int chunk) { return min(32, st.ql(s) - 256 * chunk - 32 * qw); };
+    auto issue_q = [&](int s, int chunk, int h) {
+        const int nq = rows_of(s, chunk);
+        const long row0 = (long)st.qs(s) + 256 * chunk + 32 * qw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh_dma(qg + row0 * p.q_stride + h * 64, nq, qsb, qvoff ^ (16 * (j & 1)), 8 * j * qsb, &qst[wave][8 * j * 64]);
+        vm += 4;
+    };
+    ShSlot S;
+    auto activate = [&](int sg, int chunk, bool zero_q) {
+        // `z` is an opaque zero: whatever is added to it cannot be precomputed outside the tile loop (four staging addresses and
+        // a row index kept across the loop were spilled to scratch, and a scratch reload waits for vmcnt(0): the DMA queue)
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        S.nq = rows_of(sg, chunk);
+        S.row = st.qs(sg) + 256 * chunk + 32 * qw + z + r;
+        const bf16* src = &qst[wave][0];
+        const int qbase = ad.krow0 + z;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 raw = sh_ld8(src + (qbase ^ (16 * ks)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S.q[ks][j] = (bf16)((float)raw[j] * cq);
+        }
+        if (zero_q)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) S.q[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S.o[d][i] = 0.f;
+        S.mref = 0.f; S.lsum = 0.f;
+        S.ext = hh == 0 ? sh_pack2(-0.f, 1.0f) : 0u;
+    };
+    // this wave's next target, scanning forward from (head hi, pass pi, segment s0): the (head, pass[, segment]) at which it has
+    // queries.  Global role: passes with a global segment; local role: segments with keys in passes that carry local chunks.
+    int nh = -1, np_ = 0, nsg = 0, mark = 0;
+    auto find_next = [&](int hi, int pi, int s0) {
+        nh = -1;
+        for (; hi < hpb; ++hi, pi = 0, s0 = 0)
+            for (; pi < npass; ++pi, s0 = 0) {
+                const int pinf = p_info(pi);
+                if (!local) {
+                    const int gs = (pinf & 255) - 1;
+                    if (gs >= 0 && rows_of(gs, (pinf >> 8) & 255) > 0) { nh = hi; np_ = pi; nsg = gs; return; }
+                } else {
+                    const int c = (pinf >> 16) - 1;
+                    if (c < 0) continue;
+                    for (int s = s0; s < fus; ++s)
+                        if (st.kl(s) > 0 && rows_of(s, c) > 0) { nh = hi; np_ = pi; nsg = s; return; }
+                }
+            }
+    };
+    auto chunk_of = [&](int pi) { const int pinf = p_info(pi); return local ? (pinf >> 16) - 1 : (pinf >> 8) & 255; };
+
+    // ---- prologue: the first Q rows and the first SH_D tiles
+    find_next(0, 0, 0);
+    if (nh >= 0) issue_q(nsg, chunk_of(np_), h0 + nh);
+    mark = vm;
+    for (int i = 0; i < SH_D && i < G; ++i) issue_ring();
+
+    bool act = false, fresh = false;
+    int t = 0, pi = 0, hi = 0;
+    constexpr bool ST = MODE == 3;
+    unsigned long long tt[16], tl = 0, t_loop = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[i] = 0;
+    if (ST) { tl = sh_now(); t_loop = tl; }
+    int stage = 0;                                                  // ring stage of tile g
+    for (int g = 0; g < G; ++g) {
+        if (wave == 12 + (g & 3)) sh_wait_vm(vm - myseq);         // the pieces of tile g were mine to fetch
+        SH_T(0);
+        __builtin_amdgcn_s_barrier();
+        SH_T(1);
+        if (lj < G) issue_ring();
+        const int tinf = t_info(t), kn = tinf & 255, sg = (tinf >> 8) & 255, fl = tinf >> 16;
+        const int h = h0 + hi;
+        SH_T(2);
+        // slot switch: a global wave at the first tile of its pass, a local wave at the first tile of its segment
+        if (nh == hi && np_ == pi && (local ? ((fl & 1) && nsg == sg) : t == 0)) {
+            unsigned long long tl2 = tl;
+            sh_wait_vm(vm - mark);
+            if (ST) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = sh_now(); tt[12] += n_ - tl2; tl2 = n_; __builtin_amdgcn_sched_barrier(0); }
+            activate(nsg, chunk_of(pi), !local && nsg != fus);
+            act = true; fresh = true;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ST) { const unsigned long long n_ = sh_now(); tt[13] += n_ - tl2; tl2 = n_; __builtin_amdgcn_sched_barrier(0); }
+            if (local) find_next(hi, pi, sg + 1); else find_next(hi, pi + 1, 0);
+            if (ST) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = sh_now(); tt[14] += n_ - tl2; tl2 = n_; __builtin_amdgcn_sched_barrier(0); }
+            if (nh >= 0) { issue_q(nsg, chunk_of(np_), h0 + nh); mark = vm; }
+        }
+        SH_T(3);
+        if (act) {
+            unsigned kext[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) kext[kb] = hh == 0 ? sh_pack2(1.0f, (32 * kb + r >= kn) ? -1.0e30f : 0.f) : 0u;
+            if (MODE != 1) sh_attend<ST>(S, fresh, ringK[0], ringV[0], stage * 4096, ad, kext, hh, tt, tl);
+            fresh = false;
+            if (ST) tt[9] += 1;
+            if (local ? (fl & 2) != 0 : t == ntile - 1) { sh_finish(S, p, h, r, hh); act = false; vm += 5; }   // 4 row stores + lse
+            SH_T(7);
+        }
+        if (++stage == SH_NS) stage = 0;
+        if (++t == ntile) { t = 0; if (++pi == npass) { pi = 0; ++hi; } }
+    }
+    if (ST) {
+        const unsigned w = blockIdx.x * 16 + wave;
+        if (lane == 0 && w < SH_STAMP_WAVES) {
+            tt[8] = sh_now() - t_loop; tt[10] = (unsigned long long)G; tt[11] = 1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g_sh_stamps[w][i] = tt[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ host side
+static int sh_heads_per_block(int B, int H) {
+    // one workgroup per CU when the batch allows it: a block walks `hpb` heads of its sample (hpb divides H)
+    int hpb = H;
+    while (hpb > 1 && (long)B * (H / hpb) < 256) {
+        int d = hpb - 1;
+        while (d > 1 && H % d) --d;
+        hpb = d;
+    }
+    return hpb;
+}
+
+int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
+    if (d.max_tiles > SH_MAXT || d.k_stride != d.v_stride) return MMAE_ERR_ARG;
+    const int hpb = sh_heads_per_block(d.B, d.H);
+    const dim3 grid(d.B * (d.H / hpb)), blk(1024);
+    if (mode == 1) MMAE_LAUNCH(mha_sh_fwd_kernel<1>, grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH(mha_sh_fwd_kernel<2>, grid, blk, 0, st, d, hpb);
+    else if (mode == 3) MMAE_LAUNCH(mha_sh_fwd_kernel<3>, grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH(mha_sh_fwd_kernel<0>, grid, blk, 0, st, d, hpb);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}

@@ -23,6 +23,8 @@ int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const 
                          int empty_mode, int variant, void* stream);
 /* diagnostic (variant 9 of the forward): copies the 8 per-launch stamp sums to host8 and clears them (host sync). */
 int mmae_debug_mha_stamps(unsigned long long* host8);
+/* diagnostic (variant 8 of the forward, mha_sh.hip): 2 x 16 stamp sums (global-role waves, local-role waves), cleared on read */
+int mmae_debug_sh_stamps(unsigned long long* host32);
 #ifdef __cplusplus
 }
 #endif

@@ -276,7 +276,8 @@ def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
 # variant: kernel variant of csrc/mmae_internal.h (0 = what the product ABI runs: the 32x32x16 forward for dh 64; 2 = the
 # 16x16x32 forward of round 1; 4 = 32x32x16 with 256-query tiles)
 @pytest.mark.parametrize("T,dh,variant", [(torch.float32, 64, 0), (torch.float32, 32, 0), (torch.bfloat16, 64, 0),
-                                          (torch.bfloat16, 32, 0), (torch.bfloat16, 64, 2), (torch.bfloat16, 64, 4)])
+                                          (torch.bfloat16, 32, 0), (torch.bfloat16, 64, 2), (torch.bfloat16, 64, 4),
+                                          (torch.bfloat16, 64, 5)])
 @pytest.mark.parametrize("empty_mode", [0, 1])
 def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     from incomplete_multimodal_fusion_amd import ops
@@ -316,7 +317,8 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     close(kvd.grad[:, I:], v64.grad.reshape(nk, I), tol * 2, "dv")
 
 
-@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4)])
+@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4),
+                                       (torch.bfloat16, 5)])
 @pytest.mark.parametrize("shift", [0.0, -40.0])
 def test_mha_online_softmax_rescale_branch(T, variant, shift):
     """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path; the 32x32x16 forward
@@ -432,7 +434,7 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     res = []
     # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path (dh 64: 32x32x16 forward), 2: the round-1
     # 16x16x32 forward, 4: 256-query tiles, 9: the stamped diagnostic build
-    for variant in ((-1, 0, 2, 4, 9) if dh == 64 else (-1, 0)):
+    for variant in ((-1, 0, 2, 4, 5, 9) if dh == 64 else (-1, 0)):
         x = qkv.clone().requires_grad_()
         out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)
