@@ -22,7 +22,7 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 1
+#define MMAE_ABI_VERSION 2   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -38,8 +38,9 @@ int mmae_last_hip_error(void);
 int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v, void* out,
                  float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
                  const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
-                 int max_q_rows, float scale, int empty_mode, void* stream);
-/* backward of the above (autograd of the same lines).  delta_ws: (H, q_rows_total) fp32 scratch. */
+                 int max_q_rows, int max_k_rows, float scale, int empty_mode, void* stream);
+/* backward of the above (autograd of the same lines).  delta_ws: (3, H, q_rows_total) fp32 scratch (delta and the row
+ * constants handed from the dQ kernel to the dK/dV kernel). */
 int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                  const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
                  long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,

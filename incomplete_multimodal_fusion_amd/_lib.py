@@ -63,8 +63,9 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = ret
             fn.argtypes = argtypes
-        if l.mmae_abi_version() != 1:
-            raise MmaeLibraryError("ABI version mismatch")
+        want = int(re.search(r"#define\s+MMAE_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read()).group(1))
+        if l.mmae_abi_version() != want:            # a stale .so against a newer header (or the reverse): rebuild
+            raise MmaeLibraryError("ABI version mismatch: library %d, include/mmae_hip.h %d" % (l.mmae_abi_version(), want))
         _lib = l
     return _lib
 

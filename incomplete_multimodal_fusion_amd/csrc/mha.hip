@@ -452,16 +452,17 @@ static int check_common(int dtype, int head_dim, int B, int H, int nseg, const v
 extern "C" int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             void* out, float* lse, long q_stride, long k_stride, long v_stride, long o_stride,
                             long q_rows_total, const int* q_seg_start, const int* q_seg_len, const int* k_seg_start,
-                            const int* k_seg_len, int max_q_rows, float scale, int empty_mode, int variant, void* stream) {
+                            const int* k_seg_len, int max_q_rows, int max_k_rows, float scale, int empty_mode, int variant,
+                            void* stream) {
     int rc = check_common(dtype, head_dim, B, H, nseg, q, k, v, q_stride, k_stride, v_stride, q_seg_start, q_seg_len,
                           k_seg_start, k_seg_len);
     if (rc) return rc;
-    if (!out || !lse || !al16(out) || (o_stride % 8) || max_q_rows < 0 || q_rows_total <= 0) return MMAE_ERR_ARG;
+    if (!out || !lse || !al16(out) || (o_stride % 8) || max_q_rows < 0 || max_k_rows < 0 || q_rows_total <= 0) return MMAE_ERR_ARG;
     MhaDesc d{};
     d.q = q; d.k = k; d.v = v; d.o = out; d.lse = lse;
     d.q_stride = q_stride; d.k_stride = k_stride; d.v_stride = v_stride; d.o_stride = o_stride;
     d.q_start = q_seg_start; d.q_len = q_seg_len; d.k_start = k_seg_start; d.k_len = k_seg_len;
-    d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_tiles = max_q_rows / 64 + nseg;
+    d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_tiles = max_q_rows / 64 + nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows;
     d.scale = scale; d.empty_mode = empty_mode;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st)) : mha_bf16_fwd(d, head_dim, variant, st);
@@ -471,10 +472,10 @@ extern "C" int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int n
 extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             void* out, float* lse, long q_stride, long k_stride, long v_stride, long o_stride,
                             long q_rows_total, const int* q_seg_start, const int* q_seg_len, const int* k_seg_start,
-                            const int* k_seg_len, int max_q_rows, float scale, int empty_mode, void* stream) {
+                            const int* k_seg_len, int max_q_rows, int max_k_rows, float scale, int empty_mode, void* stream) {
     return mmae_mha_fwd_variant(dtype, head_dim, B, H, nseg, q, k, v, out, lse, q_stride, k_stride, v_stride, o_stride,
-                                q_rows_total, q_seg_start, q_seg_len, k_seg_start, k_seg_len, max_q_rows, scale, empty_mode,
-                                0, stream);
+                                q_rows_total, q_seg_start, q_seg_len, k_seg_start, k_seg_len, max_q_rows, max_k_rows, scale,
+                                empty_mode, 0, stream);
 }
 
 extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
@@ -496,7 +497,7 @@ extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int n
     d.q_stride = q_stride; d.k_stride = k_stride; d.v_stride = v_stride; d.o_stride = o_stride; d.do_stride = do_stride;
     d.dq_stride = dq_stride; d.dk_stride = dk_stride; d.dv_stride = dv_stride;
     d.q_start = q_seg_start; d.q_len = q_seg_len; d.k_start = k_seg_start; d.k_len = k_seg_len;
-    d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg;
+    d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows;
     d.scale = scale; d.empty_mode = empty_mode;
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

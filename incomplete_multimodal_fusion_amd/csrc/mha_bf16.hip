@@ -398,7 +398,11 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
         }
         const float delta = rows_sum(dpart);
         const float lse2 = (qvalid[qb] ? p.lse[(long)h * p.stat_stride + qrow0 + myq[qb]] : 0.f) * LOG2E;
-        if (qvalid[qb] && g == 0) p.delta[(long)h * p.stat_stride + qrow0 + myq[qb]] = delta;
+        if (qvalid[qb] && g == 0) {
+            // plane 0: delta; planes 1 / 2: the row constants as the key-stationary kernels seed them (-lse in the log2 domain, -delta)
+            const long at = (long)h * p.stat_stride + qrow0 + myq[qb], plane = (long)p.H * p.stat_stride;
+            p.delta[at] = delta; p.delta[at + plane] = -lse2; p.delta[at + 2 * plane] = -delta;
+        }
         neg_lse4[qb] = f32x4{-lse2, -lse2, -lse2, -lse2};
         neg_delta4[qb] = f32x4{-delta, -delta, -delta, -delta};
     }
@@ -956,6 +960,9 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant >= 5 && g_variant <= 8) return mha_sh_fwd(d, g_variant - 5, st);   // sample-head forward (mha_sh.hip); 6 / 7 / 8: diagnostics
+    // default: the sample-head kernel wherever a sample has enough query rows to fill its 16 waves (encoder blocks); the
+    // tile-per-block kernel below for the few-query calls (attention pooling, contrastive pools: 1-8 queries per sample)
+    if (head_dim == 64 && g_variant == 0 && mha_sh_applicable(d)) return mha_sh_fwd(d, 0, st);
     if (head_dim == 64 && (g_variant == 0 || g_variant == 3 || g_variant == 4 || g_variant == 9)) {
         // default (0 == 3): 32x32x16 forward, 4 waves x 32 queries = 128-query tiles; 4: 256-query tiles; 9: stamped diagnostic
         MhaDesc e = d;
@@ -989,6 +996,10 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
     else MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<32>), dim3(xcd_grid(d.B, d.H, max_q_tiles)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();
     d.max_tiles = max_k_tiles;
+    // dK / dV: the key-stationary sample-head kernel (mha_sh.hip) where a sample has enough keys to fill it (encoder blocks) or
+    // when asked for (variant 5: tests); variant 3 = the tile-per-block kernels of round 2 throughout
+    if (head_dim == 64 && mha_sh_dkdv_supported(d) && (g_variant == 5 || (g_variant == 0 && d.max_k_rows >= 128))) return mha_sh_dkdv(d, 0, st);
+    if (head_dim == 64 && mha_sh_dkdv_supported(d) && (g_variant == 6 || g_variant == 7)) return mha_sh_dkdv(d, g_variant - 5, st);   // diagnostics: stream only / no ring DMA
     if (head_dim == 64) MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<64>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
     else MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<32>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
     MMAE_CHECK_LAUNCH();

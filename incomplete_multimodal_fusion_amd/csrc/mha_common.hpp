@@ -15,6 +15,7 @@ struct MhaDesc {
     const int* q_start; const int* q_len; const int* k_start; const int* k_len;   // (B, nseg) each
     long stat_stride;        // q_rows_total
     int B, H, nseg, max_tiles;
+    int max_q_rows, max_k_rows;   // upper bounds of a sample's query / key rows (all segments): kernel selection only
     float scale;
     int empty_mode;
 };
@@ -54,4 +55,7 @@ __device__ __forceinline__ TileSel select_tile(const int* len, int nseg, int t) 
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int variant, hipStream_t st);
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int variant, hipStream_t st);
 // sample-head kernels (mha_sh.hip): bf16, head_dim 64; d.max_tiles = key tiles per sample (upper bound)
-int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st);   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics
+bool mha_sh_applicable(const MhaDesc& d);
+int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st);
+bool mha_sh_dkdv_supported(const MhaDesc& d);
+int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st);   // needs workspace planes 1, 2 (see mha_bf16_bwd_dq_kernel)   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics

@@ -110,6 +110,15 @@ __device__ __forceinline__ void sh_dma(const bf16* base, int n_rows, int row_byt
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds_piece, 16, voff, sh_uni(soff), 0, 0);
 }
 
+// 64 floats (row constants), 4 bytes per lane; entries >= n read as 0
+__device__ __forceinline__ void sh_dma4(const float* base, int n, float* lds, int lane) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    float* ub = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, sh_uni(n * 4), 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds, 4, lane * 4, 0, 0, 0);
+}
+
 // transposed operand of the 32x32x16 products: element j of lane (r = lane & 31, hh = lane >> 5) is
 // X[base + 8 (j >> 2) + 4 hh + (j & 3)][32 dhb + r] of the swizzled image (mha_bf16.hip: tr32_frag)
 __device__ __forceinline__ bf16x8 sh_tr(const bf16* img, int off0, int off1) {
@@ -183,21 +192,26 @@ __device__ __forceinline__ void sh_attend(ShSlot& s, bool fresh, const bf16* Kst
     f32x16 sacc[2];
     const bf16x8 qe = sh_ext(s.ext);
     const int kbase = ad.krow0 + stage_el, vbase = ad.tr00 + stage_el;      // element offsets incl. the ring stage (see ShAddr)
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        f32x16 z;
+        bf16x8 kf[4];                                             // the block's four K fragments are requested together
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = sh_ld8(Kst + 2048 * kb + (kbase ^ (16 * ks)));
         sacc[kb] = sh_mma(sh_ext(kext[kb]), qe, z);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sacc[kb] = sh_mma(sh_ld8(Kst + 2048 * kb + (kbase ^ (16 * ks))), s.q[ks], sacc[kb]);
+        for (int ks = 0; ks < 4; ++ks) sacc[kb] = sh_mma(kf[ks], s.q[ks], sacc[kb]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // emitted order: 4 LDS reads, then the 5 products
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
     }
     if (ST) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");    // let the MFMA chain drain into [4]
     SH_T(4);
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mx0 = fmaxf(sacc[0][0], sacc[0][1]), mx1 = fmaxf(sacc[1][0], sacc[1][1]);      // two independent max3 chains
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, sacc[0][i]), sacc[1][i]);
-    mx = sh_swap_max(mx);
+    for (int i = 2; i < 16; i += 2) { mx0 = fmaxf(fmaxf(mx0, sacc[0][i]), sacc[0][i + 1]); mx1 = fmaxf(fmaxf(mx1, sacc[1][i]), sacc[1][i + 1]); }
+    const float mx = sh_swap_max(fmaxf(mx0, mx1));
     const bool need = fresh | (mx > SH_THR);
     if (__builtin_amdgcn_ballot_w64(need) != 0) {              // wave-uniform: first tile, or some row outgrew its reference
         const float want = s.mref + (fresh ? mx : fmaxf(mx, 0.f));
@@ -242,8 +256,13 @@ __device__ __forceinline__ void sh_attend(ShSlot& s, bool fresh, const bf16* Kst
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16* vb = Vst + 64 * (32 * kb + 16 * s2);
+            if (kb == 0 && s2 == 0 && fresh) {                    // a fresh slot's accumulators start from the C = 0 form: no zero fill
 #pragma unroll
-            for (int d = 0; d < 2; ++d) s.o[d] = sh_mma(sh_tr(vb, vbase ^ (32 * d), vbase ^ (32 * d + 520)), pb[kb][s2], s.o[d]);
+                for (int d = 0; d < 2; ++d) s.o[d] = sh_mma(sh_tr(vb, vbase ^ (32 * d), vbase ^ (32 * d + 520)), pb[kb][s2], z);
+            } else {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) s.o[d] = sh_mma(sh_tr(vb, vbase ^ (32 * d), vbase ^ (32 * d + 520)), pb[kb][s2], s.o[d]);
+            }
         }
         if (kb == 0) __builtin_amdgcn_sched_barrier(0);           // at most 8 transposed fragments in flight (VGPR budget: 128)
     }
@@ -410,11 +429,7 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
         if (zero_q)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) S.q[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S.o[d][i] = 0.f;
-        S.mref = 0.f; S.lsum = 0.f;
+        S.mref = 0.f; S.lsum = 0.f;                               // (the accumulators are defined by the first PV product)
         S.ext = hh == 0 ? sh_pack2(-0.f, 1.0f) : 0u;
     };
     // this wave's next target, scanning forward from (head hi, pass pi, segment s0): the (head, pass[, segment]) at which it has
@@ -498,6 +513,270 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------ backward: dK, dV
+// Key-stationary counterpart of the forward kernel.  One 12-wave workgroup per sample walks its heads; a wave owns 32 keys
+// ("key block": K and V fragments in registers, dK^T / dV^T accumulators in registers -- 168 VGPRs, three waves per SIMD) and
+// the workgroup sweeps the 64-row query tiles that may attend the 12 key blocks of the current PASS.  Q / dO tiles and their
+// row constants (-lse in the log2 domain, -delta: planes 1 and 2 of the workspace, written by the dQ kernel) arrive by
+// LDS-DMA into a 3-stage ring, fetched once per pass by a rotating loader wave; the key blocks of the NEXT pass are prefetched
+// into wave-private staging.  Per (64 queries x 32 keys): S = Q K~^T and dP = dO V^T with the row constants as the initial
+// accumulators (the query sits on the accumulator register index, so the seed is a 16-float vector read from LDS), P = exp2(S),
+// dS = P o dP', then dV^T += dO^T P and dK^T += Q^T dS with the transposed operands read straight from the row-major images:
+// 32 MFMAs per ~100 VALU instructions.  No per-element masks: padded query rows are zero rows with zero constants (the DMA's
+// range check), padded keys only pollute their own never-stored columns.
+#define SD_NS 3                 // ring stages
+#define SD_D 2                  // tiles in flight ahead of the consumer
+#define SD_W 12                 // waves = key blocks per pass
+#define SD_MAXB 64              // key blocks per sample (one lane each)
+#define SD_MAXS 64              // ring steps per head (one lane each)
+
+template <int MODE>
+__global__ __launch_bounds__(SD_W * 64) void mha_sh_dkdv_kernel(MhaDesc p, int hpb) {
+    __shared__ __attribute__((aligned(1024))) bf16 ringQ[SD_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 ringO[SD_NS][4096];
+    __shared__ __attribute__((aligned(1024))) float ringL[SD_NS][128];       // [0..63] -lse2, [64..127] -delta of the tile's rows
+    __shared__ __attribute__((aligned(1024))) bf16 kst[SD_W][2][32 * 64];    // wave-private K / V staging of the next pass's key block
+    __shared__ int kb_row_s[SD_MAXB], kb_info_s[SD_MAXB];                    // key blocks (read at pass switches only: not worth two VGPRs)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = sh_uni(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const int hgroups = p.H / hpb;
+    const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * hpb;
+    const int nseg = p.nseg, fus = nseg - 1;
+    ShSeg st; st.load(p, b, lane);
+    // ---- schedule of this sample (registers, one lane per entry)
+    // key blocks: first row, n | seg << 8.   steps: first query row, n | seg << 8 | mode << 12 | pass << 16 | last-of-pass << 24
+    // mode 1: ordinary tile, 2: fully masked query rows attending every key uniformly (P = 1 / keys, dS = 0), 3: no-op filler
+    int kb_row = 0, kb_info = 0, st_row = 0, st_info = 0, NB = 0, nsteps = 0, npass = 0;
+    {
+        for (int s = 0; s < nseg; ++s) {
+            const int L = st.kl(s), nb = (L + 31) >> 5, j = lane - NB;
+            if (j >= 0 && j < nb) { kb_row = st.ks(s) + 32 * j; kb_info = min(32, L - 32 * j) | (s << 8); }
+            NB += nb;
+        }
+        NB = min(NB, SD_MAXB);
+        npass = (NB + SD_W - 1) / SD_W;
+        if (wave == 0) { kb_row_s[lane] = kb_row; kb_info_s[lane] = kb_info; }
+        for (int ps = 0; ps < npass; ++ps) {
+            int segmask = 0;
+            for (int w = 0; w < SD_W; ++w) {
+                const int kbi = SD_W * ps + w;
+                if (kbi < NB) segmask |= 1 << ((__builtin_amdgcn_readlane(kb_info, kbi) >> 8) & 15);
+            }
+            const int first = nsteps;
+            for (int sq = 0; sq < nseg; ++sq) {
+                const int QL = st.ql(sq);
+                if (QL == 0) continue;
+                int mode = 0;
+                if (sq == fus) mode = 1;
+                else if (st.kl(sq) > 0) mode = (segmask >> sq) & 1;
+                else if (p.empty_mode == 0) mode = 2;
+                if (!mode) continue;
+                const int nt = (QL + 63) >> 6, j = lane - nsteps;
+                if (j >= 0 && j < nt) { st_row = st.qs(sq) + 64 * j; st_info = min(64, QL - 64 * j) | (sq << 8) | (mode << 12) | (ps << 16); }
+                nsteps += nt;
+            }
+            if (nsteps == first) {                                 // a pass without queries still writes its (zero) gradients
+                if (lane == nsteps) { st_row = 0; st_info = (3 << 12) | (ps << 16); }
+                ++nsteps;
+            }
+            if (lane == nsteps - 1) st_info |= 1 << 24;
+        }
+        nsteps = min(nsteps, SD_MAXS);
+    }
+    __syncthreads();
+    if (NB == 0) return;
+    auto s_row = [&](int i) { return __builtin_amdgcn_readlane(st_row, i); };
+    auto s_info = [&](int i) { return __builtin_amdgcn_readlane(st_info, i); };
+
+    const bf16* qg = reinterpret_cast<const bf16*>(p.q);
+    const bf16* dog = reinterpret_cast<const bf16*>(p.dout);
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    const int qsb = (int)p.q_stride * 2, dosb = (int)p.do_stride * 2, ksb = (int)p.k_stride * 2, vsb = (int)p.v_stride * 2;
+    // (DMA source offsets are rebuilt from the lane id at every issue, behind an opaque zero: kept across the tile loop they were
+    // what the register allocator spilled)
+    auto dma_voff = [&](int row_bytes, int z) { const int pr = (lane >> 3) + z; return pr * row_bytes + 16 * ((lane & 7) ^ sh_f(pr)); };
+    ShAddr ad; ad.init(lane);
+    const float cq = p.scale * SH_LOG2E;
+    const int G = hpb * nsteps;
+    int vm = 0, myseq = 0, mark = 0;
+    // ring: loader of step j is wave 8 + (j & 3) -- the waves that idle while the fusion keys' pass runs on eight waves
+    int lj = 0, li = 0, lh = 0, lstage = 0;
+    auto issue_ring = [&]() {
+        if (MODE != 2 && wave == 8 + (lj & 3)) {
+            const long row0 = s_row(li); const int n = s_info(li) & 255, h = h0 + lh;
+            const bf16* qb_ = qg + row0 * p.q_stride + h * 64;
+            const bf16* ob_ = dog + row0 * p.do_stride + h * 64;
+            int z = 0;
+            asm volatile("" : "+s"(z));
+            const int qv = dma_voff(qsb, z), ov = dma_voff(dosb, z);
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                sh_dma(qb_, n, qsb, qv ^ (16 * (pc & 1)), 8 * pc * qsb, &ringQ[lstage][pc * 512]);
+                sh_dma(ob_, n, dosb, ov ^ (16 * (pc & 1)), 8 * pc * dosb, &ringO[lstage][pc * 512]);
+            }
+            // row constants: 64 floats each, 4 bytes per lane
+            const float* lp = p.delta + ((long)p.H + h) * p.stat_stride + row0;
+            const float* dp = p.delta + (2L * p.H + h) * p.stat_stride + row0;
+            sh_dma4(lp, n, &ringL[lstage][0], lane);
+            sh_dma4(dp, n, &ringL[lstage][64], lane);
+            vm += 18; myseq = vm;
+        }
+        ++lj;
+        if (++lstage == SD_NS) lstage = 0;
+        if (++li == nsteps) { li = 0; ++lh; }
+    };
+    // key-block staging of pass ps, head h: this wave's 32 keys -> kst[wave][0 = K, 1 = V]
+    auto kb_of = [&](int ps) { return SD_W * ps + wave; };
+    auto issue_kv = [&](int ps, int h) {
+        const int kbi = kb_of(ps);
+        const long row0 = sh_uni(kb_row_s[kbi]); const int n = sh_uni(kb_info_s[kbi]) & 255;
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const int kv_ = dma_voff(ksb, z), vv_ = dma_voff(vsb, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sh_dma(kg + row0 * p.k_stride + h * 64, n, ksb, kv_ ^ (16 * (j & 1)), 8 * j * ksb, &kst[wave][0][8 * j * 64]);
+            sh_dma(vg + row0 * p.v_stride + h * 64, n, vsb, vv_ ^ (16 * (j & 1)), 8 * j * vsb, &kst[wave][1][8 * j * 64]);
+        }
+        vm += 8;
+    };
+
+    bf16x8 kf[4], vf[4];
+    f32x16 dk[2], dv[2];
+    int my_seg = -1, my_row = 0, my_n = 0;
+    bool have = false;
+
+    // ---- prologue
+    int nxt_ps = 0, nxt_h = 0;                                      // next (pass, head) whose key block is staged
+    bool nxt_valid = kb_of(0) < NB;
+    if (nxt_valid) issue_kv(0, h0);
+    mark = vm;
+    for (int i = 0; i < SD_D && i < G; ++i) issue_ring();
+
+    int si = 0, hi = 0, stage = 0, cur_ps = -1;
+    for (int g = 0; g < G; ++g) {
+        if (wave == 8 + (g & 3)) sh_wait_vm(vm - myseq);
+        __builtin_amdgcn_s_barrier();
+        if (lj < G) issue_ring();
+        const int inf = s_info(si), qn = inf & 255, sq = (inf >> 8) & 15, mode = (inf >> 12) & 15, ps = (inf >> 16) & 255, last = inf >> 24;
+        const int h = h0 + hi;
+        if (ps != cur_ps) {                                        // first step of a pass: take over the staged key block
+            cur_ps = ps;
+            have = kb_of(ps) < NB;
+            if (have) {
+                int z = 0;
+                asm volatile("" : "+s"(z));
+                const int kbi = kb_of(ps);
+                const int ki = sh_uni(kb_info_s[kbi]);
+                my_row = sh_uni(kb_row_s[kbi]); my_n = ki & 255; my_seg = (ki >> 8) & 15;
+                sh_wait_vm(vm - mark);
+                const int kbase = ad.krow0 + z;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 raw = sh_ld8(&kst[wave][0][0] + (kbase ^ (16 * ks)));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kf[ks][j] = (bf16)((float)raw[j] * cq);
+                    vf[ks] = sh_ld8(&kst[wave][1][0] + (kbase ^ (16 * ks)));
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // stage the key block of the next pass (or of pass 0 of the next head)
+            nxt_ps = ps + 1; nxt_h = hi;
+            if (nxt_ps == npass) { nxt_ps = 0; ++nxt_h; }
+            nxt_valid = nxt_h < hpb && kb_of(nxt_ps) < NB;
+            if (nxt_valid) { issue_kv(nxt_ps, h0 + nxt_h); mark = vm; }
+        }
+        const bool part = have && (mode == 2 || (mode == 1 && (sq == fus || sq == my_seg)));
+        if (part && MODE != 1) {
+            const bf16* Qs = ringQ[0]; const bf16* Os = ringO[0];
+            const int sel = stage * 4096;
+            const int rbase = ad.krow0 + sel, tbase = ad.tr00 + sel;
+            const float* Ls = &ringL[stage][0];
+            f32x16 z16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                // S first, packed to bf16 P as soon as it is exponentiated, THEN the dP chain: 24 live accumulator registers
+                // instead of 32 (the kernel sits on the 168-VGPR line; the price is 16 shifts to widen P again for dS = P o dP')
+                bf16x8 pb[2], dsb[2];
+                {
+                    f32x16 sacc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(Ls + 32 * qb + 8 * j + 4 * hh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sacc[4 * j + i] = a[i];
+                    }
+                    if (mode == 1)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) sacc = sh_mma(sh_ld8(Qs + 2048 * qb + (rbase ^ (16 * ks))), kf[ks], sacc);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pb[s2][j] = (bf16)sh_exp2(sacc[8 * s2 + j]);   // (uniform rows: 2^(-lse2) = 1 / keys)
+                }
+                if (mode == 1) {
+                    f32x16 dpacc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(Ls + 64 + 32 * qb + 8 * j + 4 * hh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dpacc[4 * j + i] = c[i];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) dpacc = sh_mma(sh_ld8(Os + 2048 * qb + (rbase ^ (16 * ks))), vf[ks], dpacc);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dsb[s2][j] = (bf16)((float)pb[s2][j] * dpacc[8 * s2 + j]);
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) dsb[s2] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});     // uniform rows: dS = 0
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int ro = 64 * (32 * qb + 16 * s2);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        dv[d] = sh_mma(sh_tr(Os + ro, tbase ^ (32 * d), tbase ^ (32 * d + 520)), pb[s2], dv[d]);
+                        dk[d] = sh_mma(sh_tr(Qs + ro, tbase ^ (32 * d), tbase ^ (32 * d + 520)), dsb[s2], dk[d]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (last && have) {                                        // last step of the pass: this key block's gradients are complete
+            const bool valid = r < my_n;
+            bf16* dkp = reinterpret_cast<bf16*>(p.dk) + (long)(my_row + r) * p.dk_stride + h * 64 + 8 * hh;
+            bf16* dvp = reinterpret_cast<bf16*>(p.dv) + (long)(my_row + r) * p.dv_stride + h * 64 + 8 * hh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    unsigned a0 = sh_pack2(dk[d][4 * i] * p.scale, dk[d][4 * i + 1] * p.scale), a1 = sh_pack2(dk[d][4 * i + 2] * p.scale, dk[d][4 * i + 3] * p.scale);
+                    unsigned b0 = sh_pack2(dk[d][4 * i + 4] * p.scale, dk[d][4 * i + 5] * p.scale), b1 = sh_pack2(dk[d][4 * i + 6] * p.scale, dk[d][4 * i + 7] * p.scale);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+                    if (valid) *reinterpret_cast<u32x4*>(dkp + 32 * d + 8 * i) = u32x4{a0, a1, b0, b1};
+                    unsigned c0 = sh_pack2(dv[d][4 * i], dv[d][4 * i + 1]), c1 = sh_pack2(dv[d][4 * i + 2], dv[d][4 * i + 3]);
+                    unsigned e0 = sh_pack2(dv[d][4 * i + 4], dv[d][4 * i + 5]), e1 = sh_pack2(dv[d][4 * i + 6], dv[d][4 * i + 7]);
+                    auto r2 = __builtin_amdgcn_permlane32_swap(c0, e0, false, false); c0 = r2[0]; e0 = r2[1];
+                    auto r3 = __builtin_amdgcn_permlane32_swap(c1, e1, false, false); c1 = r3[0]; e1 = r3[1];
+                    if (valid) *reinterpret_cast<u32x4*>(dvp + 32 * d + 8 * i) = u32x4{c0, c1, e0, e1};
+                }
+            vm += 8;
+        }
+        if (++stage == SD_NS) stage = 0;
+        if (++si == nsteps) { si = 0; ++hi; cur_ps = -1; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ host side
 static int sh_heads_per_block(int B, int H) {
     // one workgroup per CU when the batch allows it: a block walks `hpb` heads of its sample (hpb divides H)
@@ -510,14 +789,37 @@ static int sh_heads_per_block(int B, int H) {
     return hpb;
 }
 
+bool mha_sh_applicable(const MhaDesc& d) {
+    return d.max_q_rows >= 128 && d.max_k_rows / 64 + d.nseg <= SH_MAXT && d.k_stride == d.v_stride && d.nseg <= MAXSEG &&
+           d.max_q_rows / 256 + 2 * d.nseg <= SH_MAXP;
+}
+
 int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
-    if (d.max_tiles > SH_MAXT || d.k_stride != d.v_stride) return MMAE_ERR_ARG;
+    if (d.max_k_rows / 64 + d.nseg > SH_MAXT || d.k_stride != d.v_stride || d.nseg > MAXSEG) return MMAE_ERR_ARG;
     const int hpb = sh_heads_per_block(d.B, d.H);
     const dim3 grid(d.B * (d.H / hpb)), blk(1024);
     if (mode == 1) MMAE_LAUNCH(mha_sh_fwd_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_fwd_kernel<2>, grid, blk, 0, st, d, hpb);
     else if (mode == 3) MMAE_LAUNCH(mha_sh_fwd_kernel<3>, grid, blk, 0, st, d, hpb);
     else MMAE_LAUNCH(mha_sh_fwd_kernel<0>, grid, blk, 0, st, d, hpb);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+// key-stationary dK / dV (mha_sh_dkdv_kernel): needs planes 1 (-lse * log2 e) and 2 (-delta) of the workspace d.delta, which the
+// dQ kernel of mha_bf16.hip writes next to delta itself (plane 0)
+bool mha_sh_dkdv_supported(const MhaDesc& d) {
+    const int nb = d.max_k_rows / 32 + d.nseg, passes = (nb + SD_W - 1) / SD_W;
+    return nb <= SD_MAXB && d.nseg <= MAXSEG && passes * (d.max_q_rows / 64 + d.nseg + 1) <= SD_MAXS;
+}
+
+int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st) {
+    if (!mha_sh_dkdv_supported(d)) return MMAE_ERR_ARG;
+    const int hpb = sh_heads_per_block(d.B, d.H);
+    const dim3 grid(d.B * (d.H / hpb)), blk(SD_W * 64);
+    if (mode == 1) MMAE_LAUNCH(mha_sh_dkdv_kernel<1>, grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH(mha_sh_dkdv_kernel<2>, grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH(mha_sh_dkdv_kernel<0>, grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

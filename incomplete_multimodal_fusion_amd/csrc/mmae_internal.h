@@ -14,7 +14,7 @@ extern "C" {
 int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v, void* out,
                          float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
                          const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
-                         int max_q_rows, float scale, int empty_mode, int variant, void* stream);
+                         int max_q_rows, int max_k_rows, float scale, int empty_mode, int variant, void* stream);
 int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                          const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
                          long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,

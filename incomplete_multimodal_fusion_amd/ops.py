@@ -328,7 +328,7 @@ class _MHA(torch.autograd.Function):
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
              ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(lse),
              qt.stride(0), kv.stride(0), kv.stride(0), out.stride(0), qt.shape[0],
-             ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length), qseg.max_rows, scale, empty_mode,
+             ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length), qseg.max_rows, kseg.max_rows, scale, empty_mode,
              *((variant,) if variant else ()), stream())
         if timed:
             ev1.record()
@@ -349,7 +349,8 @@ class _MHA(torch.autograd.Function):
         # every row of q / kv belongs to exactly one segment unless the Segments say otherwise (then: zero-filled)
         gq = torch.empty_like(qt) if (qseg.covers_all and (not same or kseg.covers_all)) else torch.zeros_like(qt)
         gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
-        delta = torch.empty_like(lse)
+        # workspace: delta plus, for the bf16 kernels, the row constants of the key-stationary dK/dV kernel (3 planes of (H, rows))
+        delta = torch.empty((3,) + tuple(lse.shape), dtype=lse.dtype, device=lse.device)
         es = qt.element_size()
         call("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),

@@ -30,7 +30,7 @@ def test_attention_argument_checks():
 
     def fwd(dtype=1, dh=64, B=1, H=8, nseg=4, q=a16, stride=1536, seg=a16, rows=64):
         return l.mmae_mha_fwd(dtype, dh, B, H, nseg, P(q), P(a16), P(a16), P(a16), P(a16), stride, stride, stride, 512, rows,
-                              P(seg), P(a16), P(a16), P(a16), 64, 0.125, 0, None)
+                              P(seg), P(a16), P(a16), P(a16), 64, 64, 0.125, 0, None)
     assert fwd(dh=48) == -1                 # head_dim 32 / 64 only
     assert fwd(dtype=7) == -1               # fp32 / bf16 only
     assert fwd(q=a16 + 2) == -1             # operands must be 16-byte aligned

@@ -17,7 +17,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "missing export: " + name
-    assert _lib.lib().mmae_abi_version() == 1
+    assert _lib.lib().mmae_abi_version() == 2
     # pure host helpers (no GPU needed)
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(1000, 768) == 250 * 4 * 768
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(40960, 768) == 1024 * 4 * 768
@@ -30,7 +30,7 @@ def test_invalid_arguments_are_rejected_without_launch():
     l = _lib.lib()
     # null pointers / bad head dim -> MMAE_ERR_ARG, nothing touches a device
     assert l.mmae_geglu_fwd(0, 4, 8, None, None, None) == -1
-    assert l.mmae_mha_fwd(1, 48, 1, 1, 1, None, None, None, None, None, 8, 8, 8, 8, 8, None, None, None, None, 8, 1.0, 0, None) == -1
+    assert l.mmae_mha_fwd(1, 48, 1, 1, 1, None, None, None, None, None, 8, 8, 8, 8, 8, None, None, None, None, 8, 8, 1.0, 0, None) == -1
     assert l.mmae_add_ln_fwd(0, 0, 4, 6, None, None, None, None, None, None, 1e-5, None, None, 1e-5, None, None) == -1
 
 
