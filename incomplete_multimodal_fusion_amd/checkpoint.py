@@ -31,7 +31,7 @@ def _trainable(model):
     return [p for _, p in model.named_parameters() if p.requires_grad]
 
 
-def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: float = 1.0) -> dict:
+def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: float = 1.0, balancer_optimizer=None) -> dict:
     """torch.optim.AdamW state_dict in the reference trainer's layout for a torch optimizer or an engine.FlatAdamW:
     two parameter groups -- model (lr_scale 1) then loss balancer (lr_scale balancer_lr_scale; empty for
     NoWeightingStrategy) -- indexed over the trainable parameters in named_parameters() order; state only for parameters
@@ -56,16 +56,26 @@ def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: flo
               "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
               "fused": None, "decoupled_weight_decay": True}
     nb = len([p for p in balancer.parameters() if p.requires_grad]) if balancer is not None else 0
+    if balancer_optimizer is not None:                     # PretrainStep's companion AdamW of the balancer group: its state
+        bsd = balancer_optimizer.state_dict()              # is indexed from 0 there, from len(params) in the joint layout
+        for i, st in bsd["state"].items():
+            state[len(params) + int(i)] = st
     groups = [dict(common, lr_scale=g.get("lr_scale", 1.0), params=list(range(len(params)))),
               dict(common, lr_scale=balancer_lr_scale, params=list(range(len(params), len(params) + nb)))]
     return {"state": state, "param_groups": groups}
 
 
-def load_optimizer_state_dict(optimizer, model, sd: dict):
-    """Accepts the reference layout (two groups over the trainable parameters) written by either optimizer."""
+def load_optimizer_state_dict(optimizer, model, sd: dict, balancer_optimizer=None):
+    """Accepts the reference layout (two groups over the trainable parameters) written by either optimizer.
+    balancer_optimizer: PretrainStep.balancer_opt (flat engine + trainable loss balancer) -- receives the second group."""
     if isinstance(optimizer, torch.optim.Optimizer):
         optimizer.load_state_dict(sd)
         return
+    if balancer_optimizer is not None and len(sd["param_groups"]) > 1:
+        n0 = len(sd["param_groups"][0]["params"])
+        bsd = balancer_optimizer.state_dict()
+        bsd["state"] = {int(i) - n0: st for i, st in sd["state"].items() if int(i) >= n0}
+        balancer_optimizer.load_state_dict(bsd)
     params = _trainable(model)
     n_model = len(sd["param_groups"][0]["params"])
     if n_model != len(params):
@@ -92,12 +102,15 @@ def load_optimizer_state_dict(optimizer, model, sd: dict):
     optimizer.refresh_shadow()
 
 
-def save_model(output_dir: str, epoch: int, model, optimizer, args=None, loss_scaler=None, loss_balancer=None) -> Optional[str]:
-    """checkpoint.py:75-93 -- rank 0 only."""
+def save_model(output_dir: str, epoch: int, model, optimizer, args=None, loss_scaler=None, loss_balancer=None,
+               balancer_lr_scale: float = 1.0, balancer_optimizer=None) -> Optional[str]:
+    """checkpoint.py:75-93 -- rank 0 only.  balancer_lr_scale / balancer_optimizer: the loss balancer's group of the reference
+    optimizer (PretrainStep.balancer_lr_scale / .balancer_opt when the model runs on the flat engine)."""
     if not _is_main():
         return None
     os.makedirs(output_dir, exist_ok=True)
-    to_save = {"model": model.state_dict(), "optimizer": optimizer_state_dict(optimizer, model, loss_balancer), "epoch": epoch,
+    to_save = {"model": model.state_dict(),
+               "optimizer": optimizer_state_dict(optimizer, model, loss_balancer, balancer_lr_scale, balancer_optimizer), "epoch": epoch,
                "scaler": loss_scaler.state_dict() if loss_scaler is not None else {}, "args": args}
     if loss_balancer is not None:
         to_save["loss_balancer"] = loss_balancer.state_dict()
@@ -116,15 +129,18 @@ def latest_checkpoint(output_dir: str) -> Optional[str]:
     return best_path
 
 
-def auto_load_model(output_dir: str, model, optimizer=None, loss_scaler=None, resume: str = "", map_location="cpu") -> int:
+def auto_load_model(output_dir: str, model, optimizer=None, loss_scaler=None, resume: str = "", map_location="cpu",
+                    loss_balancer=None, balancer_optimizer=None) -> int:
     """Returns the epoch to start from (0 when nothing was found).  checkpoint.py:103-132."""
     path = resume or (latest_checkpoint(output_dir) if output_dir else None)
     if not path:
         return 0
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     model.load_state_dict(ckpt["model"], strict=True)
+    if loss_balancer is not None and "loss_balancer" in ckpt:
+        loss_balancer.load_state_dict(ckpt["loss_balancer"])
     if optimizer is not None and "optimizer" in ckpt and "epoch" in ckpt:
-        load_optimizer_state_dict(optimizer, model, ckpt["optimizer"])
+        load_optimizer_state_dict(optimizer, model, ckpt["optimizer"], balancer_optimizer)
         if loss_scaler is not None and ckpt.get("scaler"):
             loss_scaler.load_state_dict(ckpt["scaler"])
         return int(ckpt["epoch"]) + 1

@@ -44,11 +44,12 @@ def init_distributed(backend: Optional[str] = None) -> bool:
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "work", "expected")
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "expected", "wire")
 
     def __init__(self):
         self.params, self.offsets = [], []
         self.flat = None
+        self.wire = None                                     # reduced-precision copy on the wire (grad_dtype), else None
         self.pending = 0
         self.expected = 0
         self.work = None
@@ -56,11 +57,17 @@ class _Bucket:
 
 class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
-                 average: bool = True, engine=None, static_unused: bool = True):
+                 average: bool = True, engine=None, static_unused: bool = True, grad_dtype: torch.dtype = torch.float32):
         """engine: an engine.FlatAdamW whose flat gradient buffer is all-reduced in place (buckets = contiguous ranges of
-        it, no staging copies); without it the reducer owns its bucket buffers."""
+        it, no staging copies); without it the reducer owns its bucket buffers.
+        grad_dtype=torch.bfloat16: the buckets cross the wire in bf16 (half the xGMI bytes) -- one cast before
+        the collective, one cast back after the wait; the accumulation inside the collective is then bf16 too.
+        After every finish(): `stats` = {'allreduce_bytes', 'buckets', 'comm_exposed_ms'} of that step (bytes each rank
+        hands to the collectives; time the compute stream spent waiting on them = communication NOT hidden by backward)."""
         self.engine = engine
         self.static_unused = bool(static_unused)
+        self.grad_dtype = grad_dtype
+        self.stats = {"allreduce_bytes": 0, "buckets": 0, "comm_exposed_ms": 0.0}
         self._next = 0
         if engine is not None:
             self._init_flat(engine, bucket_bytes, group, average)
@@ -123,18 +130,26 @@ class GradAllReducer:
     def prepare(self):
         self._seen = set()
         self._next = 0
+        self._sent_bytes, self._sent_buckets = 0, 0
         for b in self.buckets:
             b.work = None
+            b.wire = None
             b.pending = sum(1 for p in b.params if p not in self._unused)
             b.expected = b.pending
 
     def _launch(self, b: _Bucket):
         if self.engine is not None:
             self.engine.flush()                              # batched copy of the small gradients into the flat buffer
+        self._sent_bytes += b.flat.numel() * (2 if self.grad_dtype == torch.bfloat16 else 4)
+        self._sent_buckets += 1
         if self.world > 1:
             # RCCL averages inside the collective (ncclAvg); gloo has no AVG, finish() scales there
             self._avg_in_op = self.average and dist.get_backend(self.group) == "nccl"
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg_in_op else dist.ReduceOp.SUM,
+            buf = b.flat
+            if self.grad_dtype != torch.float32:
+                b.wire = b.flat.to(self.grad_dtype)
+                buf = b.wire
+            b.work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg_in_op else dist.ReduceOp.SUM,
                                      group=self.group, async_op=True)
         else:
             b.work = True
@@ -212,17 +227,51 @@ class GradAllReducer:
                                  device=self.buckets[0].flat.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             used = flags.tolist()                            # host sync, like DDP's local_used_map copy
+        on_gpu = self.buckets and self.buckets[0].flat.is_cuda
+        if on_gpu:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
         for b in self.buckets:
             if b.work is not True and b.work is not None:
                 b.work.wait()
+        if on_gpu:
+            ev1.record()
+        else:
+            self.stats["comm_exposed_ms"] = (time.perf_counter() - t0) * 1e3
+        for b in self.buckets:
+            if b.wire is not None:
+                b.flat.copy_(b.wire)
+                b.wire = None
             if self.average and self.world > 1 and not getattr(self, "_avg_in_op", False):
                 b.flat.mul_(1.0 / self.world)
+        self._pending_events = (ev0, ev1) if on_gpu else None
+        self.stats["allreduce_bytes"], self.stats["buckets"] = self._sent_bytes, self._sent_buckets
+        if self.static_unused and not self._first:
+            # A parameter outside the agreed unused set that got no gradient on THIS rank this step (a branch not taken here):
+            # its slot went out as zeros and came back as the average of the other ranks' gradients.  Hand it to the optimizer
+            # like everywhere else -- every rank then applies the same update (replicas cannot drift) without a collective.
+            for p in self.params:
+                if p.grad is None and p not in self._unused:
+                    bi, off = self._where[p]
+                    p.grad = self.buckets[bi].flat[off:off + p.numel()].view_as(p)
         if used is not None:
             for p, u in zip(self.params, used):
                 if u and p.grad is None:                     # used on another rank: take part in the update here too
                     bi, off = self._where[p]
                     p.grad = self.buckets[bi].flat[off:off + p.numel()].view_as(p)
         self._first = False
+
+    def exposed_ms(self) -> float:
+        """Time the compute stream waited for the collectives in the last finish() (host sync on the GPU path)."""
+        ev = getattr(self, "_pending_events", None)
+        if ev is not None:
+            ev[1].synchronize()
+            self.stats["comm_exposed_ms"] = ev[0].elapsed_time(ev[1])
+            self._pending_events = None
+        return self.stats["comm_exposed_ms"]
 
     def unused_parameters(self):
         return list(self._unused)

@@ -193,7 +193,7 @@ class PretrainStep:
                  sample_tasks_uniformly: bool = False, autocast: bool = True, patch_size: int = 16,
                  grad_reducer=None, side_stream_wgrad: bool = False, clip_grad: Optional[float] = None,
                  skip_grad: Optional[float] = None, contra: str = 'dino', contra_weight: Optional[float] = None,
-                 loss_balancer=None, check_finite: bool = True):
+                 loss_balancer=None, check_finite: bool = True, balancer_lr_scale: float = 1.0):
         self.model, self.opt = model, optimizer
         self.in_domains = tuple(in_domains) if in_domains is not None else tuple(model.domains)
         self.N, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
@@ -203,6 +203,27 @@ class PretrainStep:
         self.clip_grad, self.skip_grad, self.check_finite = clip_grad, skip_grad, check_finite
         self.contra, self.contra_weight, self.balancer = contra, contra_weight, loss_balancer
         self.contra_loss = HardNegtive_loss() if contra == 'hardneg' else None
+        # The reference optimises the loss balancer's parameters (UncertaintyWeightingStrategy.log_vars) as the second group of
+        # its AdamW (utils/optim_factory.py:136-150, lr x balancer lr_scale).  The flat engine holds the MODEL's parameters
+        # only, so a trainable balancer next to a FlatAdamW gets a small companion torch AdamW here -- stepped, zeroed,
+        # all-reduced and checkpointed with the step (it used to be silently left un-trained with an accumulating .grad).
+        from .engine import FlatAdamW
+        self.balancer_lr_scale = balancer_lr_scale
+        self.balancer_opt = None
+        bal = [p for p in loss_balancer.parameters() if p.requires_grad] if isinstance(loss_balancer, torch.nn.Module) else []
+        if bal:
+            if isinstance(optimizer, FlatAdamW):
+                held = {id(p) for p in optimizer.params}
+                bal = [p for p in bal if id(p) not in held]
+                if bal:
+                    self.balancer_opt = torch.optim.AdamW(bal, lr=optimizer.param_groups[0]["lr"] * balancer_lr_scale,
+                                                          betas=tuple(optimizer.betas), eps=optimizer.eps,
+                                                          weight_decay=optimizer.param_groups[0]["weight_decay"])
+            else:
+                held = {id(p) for g in optimizer.param_groups for p in g["params"]}
+                if any(id(p) not in held for p in bal):
+                    raise ValueError("the loss balancer has trainable parameters that the optimizer does not hold: build it "
+                                     "with create_optimizer({'model': ..., 'balancer': ...}) as the reference driver does")
         model.fuse_unpatchify_loss = True
         model.side_stream_wgrad = side_stream_wgrad
 
@@ -210,6 +231,11 @@ class PretrainStep:
         from .engine import FlatAdamW
         if isinstance(self.opt, FlatAdamW):
             self.opt.step(clip_grad=self.clip_grad, skip_grad=self.skip_grad, check_finite=self.check_finite)
+            if self.balancer_opt is not None:
+                for g in self.balancer_opt.param_groups:       # follows the engine's schedule (the driver sets lr per step)
+                    g["lr"] = self.opt.param_groups[0]["lr"] * self.balancer_lr_scale
+                    g["weight_decay"] = self.opt.param_groups[0]["weight_decay"]
+                self.balancer_opt.step()
             return
         params = [p for g in self.opt.param_groups for p in g['params'] if p.grad is not None]
         if self.clip_grad is not None:
@@ -228,12 +254,20 @@ class PretrainStep:
             task_losses, loss_contra, loss = step_losses(out, tasks_dict, out[1], self.patch, self.loss_fns,
                                                          self.contra_weight, self.contra, self.balancer, self.contra_loss)
         self.opt.zero_grad(set_to_none=True)               # (FlatAdamW: also clears the flat gradient buffer)
+        if self.balancer_opt is not None:
+            self.balancer_opt.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.prepare()
         loss.backward()
         ops.join_wgrad_stream()
         if self.reducer is not None:
             self.reducer.finish()
+            if self.balancer_opt is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                for g in self.balancer_opt.param_groups:       # a handful of scalars: one tiny all-reduce each
+                    for q in g["params"]:
+                        if q.grad is not None:
+                            torch.distributed.all_reduce(q.grad)
+                            q.grad.div_(torch.distributed.get_world_size())
         self._optimizer_step()
         return {'loss': loss.detach(), 'loss_contra': loss_contra.detach(),
                 **{k + '_loss': v.detach() for k, v in task_losses.items()}}

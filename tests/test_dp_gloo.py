@@ -216,3 +216,77 @@ def _worker_mixed(rank, world, port, q):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         _worker_dynamic(rank, world, port, q, True)
+
+
+# static set agreed on step 0 (both ranks use the side branch); on step 1 rank 0 does NOT take it: its slot goes out as zeros
+_SIDE_LATE = {(0, 0): True, (0, 1): True, (1, 0): False, (1, 1): True, (2, 0): True, (2, 1): False}
+
+
+def _worker_late(rank, world, port, q, grad_dtype):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from incomplete_multimodal_fusion_amd import dp
+    assert dp.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    net = Branchy()
+    red = dp.GradAllReducer(net.parameters(), bucket_bytes=1500, static_unused=True,
+                            grad_dtype=torch.bfloat16 if grad_dtype == "bf16" else torch.float32)
+    torch.manual_seed(100)
+    X = torch.randn(8, 16); Y = torch.randn(8, 4)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    res = []
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        red.prepare()
+        ((net(xs, _SIDE_LATE[(step, rank)]) - ys) ** 2).mean().backward()
+        red.finish()
+        res.append(({n: (None if p.grad is None else p.grad.tolist()) for n, p in net.named_parameters()}, dict(red.stats),
+                    red.exposed_ms()))
+    q.put((rank, res, red.static_unused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_static_set_parameter_without_a_local_gradient_gets_the_average_on_every_rank(grad_dtype):
+    """with the static unused set, a parameter outside it that gets no gradient on ONE rank in a later step must
+    still be updated there with the all-reduced average (else the replicas drift).  Also: the per-step `stats`, and
+    grad_dtype=bf16 buckets -- the averaged gradient within bf16 rounding of the fp32 one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_late, args=(r, 2, port, q, grad_dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    nparams = sum(p.numel() for p in Branchy().parameters())
+    for step in range(3):
+        locals_ = []
+        for rank in range(2):
+            torch.manual_seed(0)
+            net = Branchy()
+            torch.manual_seed(100)
+            X = torch.randn(8, 16); Y = torch.randn(8, 4)
+            xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+            ((net(xs, _SIDE_LATE[(step, rank)]) - ys) ** 2).mean().backward()
+            locals_.append({n: p.grad for n, p in net.named_parameters()})
+        for rank, res, static in out:
+            assert static is True                                       # the ranks agreed on step 0: the set stays static
+            grads, stats, exposed = res[step]
+            assert stats["buckets"] >= 2 and stats["allreduce_bytes"] == nparams * (2 if grad_dtype == "bf16" else 4)
+            assert exposed >= 0.0
+            for n in locals_[0]:
+                gs = [l[n] for l in locals_]
+                want = sum(torch.zeros_like(next(x for x in gs if x is not None)) if g is None else g for g in gs) / 2
+                assert grads[n] is not None, (step, rank, n)            # ... also where this rank had no local gradient
+                got = torch.tensor(grads[n])
+                if grad_dtype == "fp32":
+                    assert torch.allclose(got, want, atol=1e-6), (step, rank, n)
+                else:                                                   # two bf16 roundings (cast, sum): 2^-8 relative each
+                    assert torch.allclose(got, want, atol=2e-2 * float(want.abs().max()) + 1e-6), (step, rank, n)
+        assert out[0][1][step][0] == out[1][1][step][0], "replicas hold different gradients"
