@@ -400,7 +400,9 @@ class MultiMAE(nn.Module):
         enc_rows = tokens_T[BN:]
         preds = {}
         for d, adapter in self.output_adapters.items():
-            rows = enc_rows.float() if d in fp32_output_adapters else enc_rows               # fp32 adapters (:518-527)
+            # fp32 adapters (:518-527) take the final norm's fp32 output itself, as the reference's do (layer_norm leaves an
+            # autocast region in fp32) -- not the bf16 copy widened again
+            rows = tokens[BN:] if d in fp32_output_adapters else enc_rows
             with torch.autocast("cuda", enabled=False) if d in fp32_output_adapters else _nullctx():
                 tk = adapter.forward_tokens(rows, B, P, dec_seg, once=True)
             C = adapter.num_channels

@@ -58,6 +58,46 @@ def oracle_step(state, x, masks, N, heads, dec_heads, domains=O.DOMAINS, contra=
     return flatten_step(out, losses, {n: t.grad for n, t in p.items() if t.requires_grad}, domains)
 
 
+def per_sample_oracle(state, x, masks, N, heads, dec_heads, bf16=False, domains=O.DOMAINS):
+    """What the reference arithmetic gives for a batch whose samples carry DIFFERENT masks (north_star: variable per-sample
+    token split / modality dropout).  Reference semantics are defined for batch-shared masks only (the mask of row 0 drives
+    the batch, multimae_crossattn.py:402-407), so the batch result is assembled from the oracle run on every sample alone
+    (B = 1) with its own mask, and the batch loss from the per-sample losses exactly as the batched expressions would:
+    a masked task loss is the mean over the samples whose mask row is not empty (criterion.py:107-111: per-sample ratio, then
+    nanmean; an empty row is 0 / 0 and drops out), the DINO term a mean over all samples (criterion.py:330-334).
+    Returns the flat result dict of tests/parity.py (outputs stacked over samples, losses, summed parameter gradients)."""
+    B = x[domains[0]].shape[0]
+    nvalid = {d: int((masks[d].sum(1) > 0).sum()) for d in domains}
+    p = leaf_params(state)
+    outs, task_sum, contra_sum, total = [], {d: 0.0 for d in domains}, 0.0, 0.0
+    for b in range(B):
+        xb = {k: v[b:b + 1] for k, v in x.items()}
+        mb = {k: v[b:b + 1] for k, v in masks.items()}
+        out, (tl, lc, _) = O.train_step_loss(p, xb, mb, N, heads, dec_heads, 16, domains=domains, bf16=bf16)
+        lb = lc * (0.3 / B)
+        for d in domains:
+            if int(mb[d].sum()) > 0:
+                lb = lb + tl[d] / nvalid[d]
+                task_sum[d] = task_sum[d] + float(tl[d]) / nvalid[d]
+        contra_sum += float(lc) / B
+        total += float(lb)
+        lb.backward()                                             # gradients accumulate over the samples
+        outs.append(out)
+    flat = {}
+    for d in domains:
+        flat["pred/" + d] = torch.cat([o[0][d] for o in outs])
+        flat["loss/" + d] = torch.tensor(task_sum[d])
+    flat["pooled"] = torch.cat([o[2] for o in outs]); flat["ori_tokens"] = torch.cat([o[3] for o in outs])
+    flat["fusion_tokens"] = torch.cat([o[4] for o in outs])
+    for i, d in enumerate(domains):
+        flat["ret/" + d] = torch.cat([o[5 + i] for o in outs])
+    flat["loss_contra"], flat["loss"] = torch.tensor(contra_sum), torch.tensor(total)
+    for n, t in p.items():
+        if t.requires_grad and t.grad is not None:
+            flat["grad/" + n] = t.grad
+    return {k: v.detach().double().cpu() for k, v in flat.items()}
+
+
 def native_step_flat(model, x, masks, N, autocast, fused=True, contra="dino", domains=O.DOMAINS, patch=16):
     from incomplete_multimodal_fusion_amd.pretrain import step_losses
     model.fuse_unpatchify_loss = fused

@@ -99,3 +99,30 @@ def test_c3_vitb_per_sample_modality_dropout_vs_oracle():
         close(fus[b:b + 1], ref[4], 1e-3, "fusion %d" % b)
         for r, want in zip(rets, ref[5:]):
             close(r[b:b + 1], want, 1e-3, "ret %d" % b)
+
+
+def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle():
+    """BASELINE config 3 at full width, bf16, INCLUDING the backward: ViT-B, 256 x 256, the model's own per-sample draw with
+    uniform task pre-sampling (some samples lose a modality), B = 4.  Every output, loss and parameter gradient of the native
+    batch against the per-sample assembly of the oracle (tests/parity.per_sample_oracle), anchored on the oracle's own bf16 run."""
+    from tests import parity
+    model = _model("base", 256, 35)
+    B, P, N = 4, 256, 384
+    x = {"s1": torch.randn(B, 1, 256, 256), "s2": torch.randn(B, 3, 256, 256), "dem": torch.randn(B, 1, 256, 256)}
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    model.per_sample_masks = True
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    for seed in range(6, 40):                                      # a draw in which at least one sample drops a modality
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            tm = model(xd, num_encoded_tokens=N, alphas=1.0, sample_tasks_uniformly=True)[1]
+        per_mod = torch.stack([(tm[d] == 0).sum(1) for d in O.DOMAINS], 1).cpu()
+        if (per_mod == 0).any() and (per_mod > 0).all(1).any():
+            break
+    assert (per_mod == 0).any(), per_mod.tolist()
+    masks = {d: tm[d].cpu() for d in O.DOMAINS}
+    got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True)
+    ref = parity.per_sample_oracle(state, x, masks, N, 8, 8)
+    anchor = parity.per_sample_oracle(state, x, masks, N, 8, 8, bf16=True)
+    parity.compare(got, ref, anchor, tol=1e-2)
