@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
-PROFILE_ROUNDS = ("r02", "r01")   # newest committed rocprofv3 summaries first
+PROFILE_ROUNDS = ("r03", "r02", "r01")   # newest committed rocprofv3 summaries first
 
 
 # ---------------------------------------------------------------------------------------------------------- launcher
@@ -54,19 +54,32 @@ def launch_ranks(args, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def domain_table(args):
+    """(domains, channels per domain, classes per domain or None) of the run: the 3-modality table of pretrain_mmae.py:45-72,
+    or the 4-modality one of pretrain_mmae_my.py:46-81 when 'dnw' is among the domains (s1 2 ch, s2 4 ch, class map)."""
+    from incomplete_multimodal_fusion_amd.pretrain import DOMAIN_CONF, DOMAIN_CONF_QUAD
+    doms = tuple(d for d in args.domains.split(",") if d)
+    conf = DOMAIN_CONF_QUAD if "dnw" in doms else DOMAIN_CONF
+    return doms, [conf[d]["channels"] for d in doms], [conf[d].get("num_classes") for d in doms]
+
+
 def build(args, device):
     from incomplete_multimodal_fusion_amd.pretrain import get_model
     torch.manual_seed(1234)
-    model = get_model(args.model, input_size=args.input_size, patch_size=16, decoder_dim=256, decoder_depth=2,
-                      decoder_num_heads=8)
+    doms, _, _ = domain_table(args)
+    model = get_model(args.model, in_domains=doms, input_size=args.input_size, patch_size=16, decoder_dim=256,
+                      decoder_depth=2, decoder_num_heads=8, fusion_blocks=bool(args.fusion_blocks))
     return model.to(device).train()
 
 
-def synthetic_tiles(B, size, device, seed):
+def synthetic_tiles(args, B, size, device, seed):
+    """i.i.d. N(0,1) tiles (the datasets are z-scored), a class map in [0, classes) for a class-map modality."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return {"s1": torch.randn(B, 1, size, size, generator=g).to(device),
-            "s2": torch.randn(B, 3, size, size, generator=g).to(device),
-            "dem": torch.randn(B, 1, size, size, generator=g).to(device)}
+    doms, chans, classes = domain_table(args)
+    x = {}
+    for d, c, k in zip(doms, chans, classes):
+        x[d] = (torch.randint(0, k, (B, size, size), generator=g) if k else torch.randn(B, c, size, size, generator=g)).to(device)
+    return x
 
 
 def cpu_model_name():
@@ -99,7 +112,7 @@ def cpu_baseline(args):
     del model
     B, P = args.cpu_batch, (args.input_size // 16) ** 2
     N = args.num_encoded_tokens
-    x = synthetic_tiles(B, args.input_size, "cpu", 99)
+    x = synthetic_tiles(args, B, args.input_size, "cpu", 99)
     opt = torch.optim.AdamW([t for t in p.values() if t.requires_grad], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
     heads = {"tiny": 3}.get(args.model, 8)
     from torch.distributions.dirichlet import Dirichlet
@@ -125,28 +138,65 @@ def cpu_baseline(args):
                       (args.model, args.input_size, args.input_size, B, N, len(times), t)}
 
 
-def step_flops(args, M=3):
+def step_flops(args):
     """Algorithmic FLOPs of one optimizer step per sample, SURVEY.md 8(d): MACs_fwd of the reference-dense formulation
     (Block + Block_Fusion as written + pooling heads + patch embedding + decoders), FLOPs_step = 6 * MACs_fwd (forward 2x,
     backward 4x, no recompute credit); and the same with Block_Fusion as executed here (K/V of every row once, query /
-    output / FF of the fusion slot only).  ViT-B defaults: 539.8 GF reference-dense (179.9 forward)."""
+    output / FF of the fusion slot only).  Everything follows the run's arguments (model preset, domains and their channels,
+    tile size, kept tokens, fusion blocks, contrastive head).  ViT-B 3-modality defaults: 539.8 GF reference-dense."""
     D = {"tiny": 192, "small": 384, "base": 768, "large": 1024}[args.model]
     L = {"tiny": 12, "small": 12, "base": 12, "large": 24}[args.model]
     h = {"tiny": 3}.get(args.model, 8)
+    doms, C, classes = domain_table(args)
+    M = len(doms)
     I, ffi, Dd, Ld, p = 64 * h, int(D * 8 / 3), 256, 2, 16
     P = (args.input_size // p) ** 2
     N = args.num_encoded_tokens
     S = N + P
-    C = [1, 3, 1]
     block = L * (4 * S * D * I + 2 * S * S * I + 3 * S * D * ffi)
-    fus_dense = L * (4 * P * (M + 1) * D * I + 2 * P * (M + 1) ** 2 * I + 3 * P * D * ffi)
-    fus_exec = L * (2 * S * D * I + 2 * P * D * I + 2 * P * (M + 1) * I + 3 * P * D * ffi)
+    fus_dense = L * (4 * P * (M + 1) * D * I + 2 * P * (M + 1) ** 2 * I + 3 * P * D * ffi) if args.fusion_blocks else 0
+    fus_exec = L * (2 * S * D * I + 2 * P * D * I + 2 * P * (M + 1) * I + 3 * P * D * ffi) if args.fusion_blocks else 0
     pool = (M + 1) * 2 * D * I + 2 * S * D * I + 2 * (M + 1) * S * I + 8 * (M + 1) * D * D
-    ctr = M * (2 * D * I + 8 * D * D) + 2 * N * D * I
-    embed = sum(P * c * p * p * D for c in C)
+    ctr = (M * (2 * D * I + 8 * D * D) + 2 * N * D * I) if (args.contra == "dino" and args.fusion_blocks) else 0
+    embed = sum(P * (64 if k else c) * p * p * D for c, k in zip(C, classes))     # class map: 64-wide class embedding per pixel
     dec = sum(P * D * Dd + Ld * (4 * P * Dd * Dd + 2 * P * P * Dd + 8 * P * Dd * Dd) + P * Dd * c * p * p for c in C)
     rest = pool + ctr + embed + dec
     return 6.0 * (block + fus_dense + rest), 6.0 * (block + fus_exec + rest)
+
+
+def workload_string(args, mask_desc):
+    D = {"tiny": 192, "small": 384, "base": 768, "large": 1024}[args.model]
+    L = {"tiny": 12, "small": 12, "base": 12, "large": 24}[args.model]
+    h = {"tiny": 3}.get(args.model, 8)
+    doms, C, _ = domain_table(args)
+    losses = {"dino": "MSE+L1+0.3*DINO", "hardneg": "task losses + hard-negative contrastive head", "none": "task losses only"}[args.contra]
+    return ("ViT-%s (D%d/L%d/h%dx64) %d-modality (%s) %dx%d tiles, patch 16, N=%d of %d tokens kept (%s Dirichlet alpha=1 masks "
+            "per step), %s, decoders 256/2/8, %s, fwd+bwd+AdamW"
+            % (args.model, D, L, h, len(doms), "+".join("%s:%dch" % (d, c) for d, c in zip(doms, C)), args.input_size,
+               args.input_size, args.num_encoded_tokens, len(doms) * (args.input_size // 16) ** 2, mask_desc,
+               "fusion blocks" if args.fusion_blocks else "no fusion blocks (multimae_quadruplet)", losses))
+
+
+def gemm_roofline():
+    """The dominant kernel of the step BY TIME is a library GEMM (hipBLASLt / Tensile through torch).  Its name, share of the
+    step, MFMA-busy % and held clock come from the committed rocprofv3 summaries of this command (profiles/rNN_sq_step.json:
+    the counters cannot be collected in-process); None when absent."""
+    js, rnd = _profile_json("sq_step")
+    try:
+        ks = {n: k for n, k in js["kernels"].items() if n.startswith(("Cijk", "Custom_Cijk"))}
+        name, top = max(ks.items(), key=lambda kv: kv[1]["ms"])
+        steps, step_ms = js["step"]["steps"], js["step"]["kernel_ms_per_step"]
+        gemm_ms = sum(k["ms"] for k in ks.values())
+        busy = sum(k["mfma_busy_pct"] * k["ms"] for k in ks.values()) / max(gemm_ms, 1e-9)
+        clock = top.get("clock_ghz") or 2.4
+        return {"kernel": name[:80], "bound": "mfma", "dominant_ms_per_step": round(top["ms"] / steps, 2),
+                "dominant_mfma_busy_pct": round(top["mfma_busy_pct"], 1), "dominant_clock_ghz": clock,
+                "achieved": round(top["mfma_busy_pct"] / 100.0 * MFMA_BF16_PEAK_TF * clock / 2.4, 1), "peak": MFMA_BF16_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(top["mfma_busy_pct"] / 100.0 * clock / 2.4, 3),
+                "all_gemms_ms_per_step": round(gemm_ms / steps, 2), "all_gemms_share_of_step": round(gemm_ms / steps / step_ms, 3),
+                "all_gemms_mfma_busy_pct": round(busy, 1), "source": "profiles/%s_sq_step.json" % rnd}
+    except Exception:
+        return None
 
 
 def _profile_json(stem):
@@ -219,7 +269,8 @@ def dry_main(args):
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 64))
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
-    red = dp.GradAllReducer(net.parameters(), bucket_bytes=32 << 10) if distributed else None
+    red = dp.GradAllReducer(net.parameters(), bucket_bytes=32 << 10,
+                            grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32) if distributed else None
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 64, generator=g)
 
@@ -242,7 +293,8 @@ def dry_main(args):
         loss = step()
     if distributed:
         dist.barrier()
-    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dt_local = time.perf_counter() - t0
+    tmax = torch.tensor([dt_local], dtype=torch.float64)
     wsum = torch.cat([p.detach().flatten() for p in net.parameters()]).double().sum().reshape(1)
     wall = [torch.zeros_like(wsum) for _ in range(world)]
     if distributed:
@@ -250,9 +302,21 @@ def dry_main(args):
         dist.all_gather(wall, wsum)
     else:
         wall = [wsum]
+    diag = {}
+    if red is not None:
+        ex = torch.tensor([red.exposed_ms()], dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([dt_local], dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [1e3 * float(v) / args.steps for v in allv]
+        diag = {"dp": {"ranks_reported_by_backend": dist.get_world_size(), "allreduce_bytes_per_step": red.stats["allreduce_bytes"],
+                       "buckets_per_step": red.stats["buckets"], "grad_wire_dtype": args.grad_dtype,
+                       "comm_exposed_ms_last_step_max_over_ranks": round(float(ex.item()), 3),
+                       "rank_ms_per_step_min": round(min(per_rank), 3), "rank_ms_per_step_max": round(max(per_rank), 3)}}
     if rank == 0:
         dt = float(tmax.item())
-        print(json.dumps({"metric": "launcher_dry_run", "dry_run": True, "value": round(args.batch * world * args.steps / dt, 2),
+        print(json.dumps({**diag, "metric": "launcher_dry_run", "dry_run": True, "value": round(args.batch * world * args.steps / dt, 2),
                           "unit": "rows/s (stand-in CPU module, not the product path)", "n_gpus": world, "ranks": world,
                           "backend": dist.get_backend() if distributed else "none", "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -265,24 +329,54 @@ def dry_main(args):
 
 # ---------------------------------------------------------------------------------------------------------- the run
 def timed_region(step, x, steps, distributed, device):
-    """barrier + synchronize | K steps | synchronize + barrier; MAX over ranks (contract of the driver)."""
+    """barrier + synchronize | K steps | synchronize + barrier; MAX over ranks (contract of the driver).
+    Also returns this rank's per-step durations (HIP events recorded behind every step, read after the region: no extra
+    synchronisation inside it) and the ranks' own wall times (what a bad scaling curve is made of)."""
     import torch.distributed as dist
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         losses = step(x)
+        marks[i + 1].record()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    ranks_dt = [dt_local]
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return float(tmax.item()), losses
+        mine = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, mine)
+        ranks_dt = [float(v.item()) for v in allv]
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return float(tmax.item()), losses, per_step, ranks_dt
+
+
+def dp_diagnostics(reducer, world, steps, ranks_dt, device, distributed):
+    """N > 1: what explains a scaling curve -- ranks the backend reports, bytes and buckets of one step's gradient exchange,
+    the time the compute stream WAITED for the collectives in the last step (communication not hidden under backward; MAX
+    over ranks), and the spread of the ranks' own step times (step = slowest rank)."""
+    import torch.distributed as dist
+    if reducer is None:
+        return {}
+    exposed = torch.tensor([reducer.exposed_ms()], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+    per_rank = [1e3 * t / steps for t in ranks_dt]
+    return {"dp": {"ranks_reported_by_backend": dist.get_world_size() if distributed else 1,
+                   "allreduce_bytes_per_step": reducer.stats["allreduce_bytes"], "buckets_per_step": reducer.stats["buckets"],
+                   "grad_wire_dtype": "bf16" if reducer.grad_dtype == torch.bfloat16 else "fp32",
+                   "comm_exposed_ms_last_step_max_over_ranks": round(float(exposed.item()), 3),
+                   "rank_ms_per_step_min": round(min(per_rank), 3), "rank_ms_per_step_max": round(max(per_rank), 3)}}
 
 
 def main():
@@ -290,7 +384,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--model", default="base")
+    ap.add_argument("--model", default="base", choices=["tiny", "small", "base", "large"])
+    ap.add_argument("--domains", default="s1,s2,dem", help="input / output modalities: s1,s2,dem (3-modality table) or "
+                    "s1,s2,dem,dnw (4-modality table: s1 2 ch, s2 4 ch, dem, dnw class map)")
+    ap.add_argument("--contra", default="dino", choices=["dino", "hardneg", "none"], help="contrastive head of the step")
+    ap.add_argument("--fusion-blocks", dest="fusion_blocks", type=int, default=1, help="0: the reference's multimae_quadruplet "
+                    "model (Zorro-masked blocks only, task losses: use --contra none)")
+    ap.add_argument("--grad-dtype", dest="grad_dtype", default="fp32", choices=["fp32", "bf16"], help="N > 1: wire dtype of the "
+                    "gradient buckets")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5's per-GPU shape: --model large --domains "
+                    "s1,s2,dem,dnw --num-encoded-tokens 512 --contra hardneg --per-sample-masks --dropout --batch 64 --clip-grad 1")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--input-size", dest="input_size", type=int, default=256)
     ap.add_argument("--num-encoded-tokens", dest="num_encoded_tokens", type=int, default=384)
@@ -317,6 +420,11 @@ def main():
     ap.add_argument("--dry-run", dest="dry_run", action="store_true", help="launcher rehearsal on CPU/gloo (see dry_main)")
     ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
     args = ap.parse_args()
+    if args.config5:
+        args.model, args.domains, args.num_encoded_tokens, args.contra = "large", "s1,s2,dem,dnw", 512, "hardneg"
+        args.per_sample, args.dropout, args.batch, args.clip_grad = True, True, 64, 1.0
+    if not args.fusion_blocks and args.contra == "dino":
+        args.contra = "none"                                  # the quadruplet model returns no contrastive tokens
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))           # nothing here has touched the GPU yet
@@ -355,15 +463,17 @@ def main():
         from incomplete_multimodal_fusion_amd.engine import FlatAdamW
         opt = FlatAdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05,
                         exclude=model.never_used_parameters())
-        reducer = dp.GradAllReducer(None, bucket_bytes=args.bucket_mb << 20, engine=opt) if distributed else None
+        gdt = torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
+        reducer = dp.GradAllReducer(None, bucket_bytes=args.bucket_mb << 20, engine=opt, grad_dtype=gdt) if distributed else None
     else:
+        gdt = torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
         opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
-        reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20) if distributed else None
+        reducer = dp.GradAllReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20, grad_dtype=gdt) if distributed else None
     model.per_sample_masks = bool(args.per_sample)
     resident_step = PretrainStep(model, opt, args.num_encoded_tokens, autocast=not args.fp32, grad_reducer=reducer,
                                  side_stream_wgrad=bool(args.side_wgrad), sample_tasks_uniformly=bool(args.dropout),
-                                 clip_grad=args.clip_grad if args.clip_grad > 0 else None)
-    x = synthetic_tiles(args.batch, args.input_size, device, 1234 + rank)
+                                 clip_grad=args.clip_grad if args.clip_grad > 0 else None, contra=args.contra)
+    x = synthetic_tiles(args, args.batch, args.input_size, device, 1234 + rank)
     torch.manual_seed(4321 + rank)
 
     def make_staged_step():
@@ -390,13 +500,15 @@ def main():
     for _ in range(args.warmup):
         losses = step(x)
     ops.set_kernel_timer([prof, prof_ln])
-    dt, losses = timed_region(step, x, args.steps, distributed, device)
+    dt, losses, per_step_ms, ranks_dt = timed_region(step, x, args.steps, distributed, device)
     ops.set_kernel_timer(None)
     loss_val = float(losses["loss"])
     assert loss_val == loss_val, "non-finite loss"
 
     # ---- secondary legs (same model / optimizer state, continuing the run; never `value`) -----------------------------
-    default_main = not (args.staging or args.per_sample or args.dropout or args.fp32)
+    default_doms = args.domains == "s1,s2,dem" and args.fusion_blocks and args.contra == "dino"
+    default_main = not (args.staging or args.per_sample or args.dropout or args.fp32) and default_doms
+    dpdiag = dp_diagnostics(reducer, world, args.steps, ranks_dt, device, distributed)
     legs = ("pcie,c3" if (world == 1 and default_main) else "") if args.legs == "auto" else \
         ("" if args.legs == "none" else args.legs)
     legs = [l for l in legs.split(",") if l]
@@ -405,7 +517,7 @@ def main():
         st = make_staged_step()
         for _ in range(2):
             st(x)
-        d2, l2 = timed_region(st, x, args.steps, distributed, device)
+        d2, l2, _, _ = timed_region(st, x, args.steps, distributed, device)
         leg_out["pcie_inclusive"] = {
             "value": round(args.batch * world * args.steps / d2, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d2 / args.steps, 3),
             "inputs": "fresh RAW host batch per step (fp32 SAR, uint8 RGB, fp32 DSM; 0.72 MB/sample): pageable->pinned ring, "
@@ -416,7 +528,7 @@ def main():
         resident_step.uniform = True
         for _ in range(2):
             resident_step(x)
-        d3, l3 = timed_region(resident_step, x, args.steps, distributed, device)
+        d3, l3, _, _ = timed_region(resident_step, x, args.steps, distributed, device)
         model.per_sample_masks = bool(args.per_sample)
         resident_step.uniform = bool(args.dropout)
         leg_out["c3_per_sample_dropout"] = {
@@ -441,12 +553,10 @@ def main():
         mask_desc = ("per-sample" if args.per_sample else "batch-shared") + (" + modality dropout" if args.dropout else "")
         out = {
             "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "median_ms_per_step": round(sorted(per_step_ms)[len(per_step_ms) // 2], 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-%s (D768/L12/h8x64) 3-modality (s1+s2+dem) %dx%d tiles, patch 16, N=%d of %d tokens "
-                                   "kept (%s Dirichlet alpha=1 masks per step), decoders 256/2/8, MSE+L1+0.3*DINO, fwd+bwd+AdamW"
-                                   % (args.model, args.input_size, args.input_size, args.num_encoded_tokens,
-                                      3 * (args.input_size // 16) ** 2, mask_desc),
+            "config": {"workload": workload_string(args, mask_desc),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "inputs": "host, PCIe inclusive" if args.staging else "resident in HBM",
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
@@ -456,17 +566,17 @@ def main():
             "roofline": {"kernel": "add_ln_bwd_kernel<bf16,bf16,3,double,nobeta>" if not args.fp32 else "add_ln_bwd_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("add_ln_bwd_kernel") if (not args.fp32 and args.batch == 256) else None,
+                         "traffic": pmc_traffic("add_ln_bwd_kernel") if (not args.fp32 and args.batch == 256 and default_doms) else None,
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n},
             # the flagship MFMA kernel of the path (north_star: fusion-attention block), mask-aware algorithmic FLOPs
-            "roofline_attention": {"kernel": "mha_bf16_fwd32_kernel<1, false>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
+            "roofline_attention": {"kernel": "mha_sh_fwd_kernel<0>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
-                         "traffic": pmc_traffic("mha_bf16_fwd") if (not args.fp32 and args.batch == 256) else None,
+                         "traffic": pmc_traffic("mha_sh_fwd") if (not args.fp32 and args.batch == 256 and default_doms) else None,
                          "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
-                         "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 512 * 2,
+                         "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 64 * {"tiny": 3}.get(args.model, 8) * 2,
                          "avg_launch_ms": round(avg_ms, 4), "avg_bracket_ms": round(raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": n_launch},
         }
@@ -481,13 +591,17 @@ def main():
                                 "flops_per_sample_reference_dense": round(dense),
                                 "achieved_reference_dense": round(value * dense / 1e12, 1),
                                 "frac_reference_dense": round(value * dense / 1e12 / peak, 4)}
+        rg = gemm_roofline()
+        if rg is not None and not args.fp32 and args.batch == 256 and default_doms:
+            out["roofline_gemm"] = rg
+        out.update(dpdiag)
         mb = mfma_busy()
-        if mb is not None and not args.fp32 and args.batch == 256:
+        if mb is not None and not args.fp32 and args.batch == 256 and default_doms:
             out["mfma_busy_pct"] = mb["pct"]
             out["mfma_busy_source"] = mb["source"]
         out.update(leg_out)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args) if default_doms else None      # the CPU leg is the headline configuration's
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
