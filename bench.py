@@ -423,8 +423,8 @@ def main():
     if args.config5:
         args.model, args.domains, args.num_encoded_tokens, args.contra = "large", "s1,s2,dem,dnw", 512, "hardneg"
         args.per_sample, args.dropout, args.batch, args.clip_grad = True, True, 64, 1.0
-    if not args.fusion_blocks and args.contra == "dino":
-        args.contra = "none"                                  # the quadruplet model returns no contrastive tokens
+    if not args.fusion_blocks:
+        args.contra = "none"                                  # the reference's quadruplet driver trains on the task losses only
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))           # nothing here has touched the GPU yet

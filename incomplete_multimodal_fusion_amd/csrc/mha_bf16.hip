@@ -989,6 +989,15 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int g_variant, hipStream_t st) {
     if (max_q_tiles > MAXT || max_k_tiles > MAXT) return MMAE_ERR_ARG;
     d.max_tiles = max_q_tiles;
+    // dQ: the tile-per-block kernel stays the default.  The query-stationary sample-head kernel (mha_sh.hip: mha_sh_dq_kernel) runs
+    // on request only (variant 5: tests, tools/bench_attn.py): its 8 KB of operand staging per wave cap it at 12 waves, i.e. 128 local
+    // query rows per pass, and the usual Dirichlet splits keep more than 128 tokens of some modality -- a second pass.  Measured at
+    // the bench shape: 349 against 378 us with equal splits, but 30 us SLOWER than this kernel at 201 / 64 / 119.
+    const bool sh_dq = head_dim == 64 && mha_sh_dq_supported(d) && (g_variant == 5 || g_variant == 6 || g_variant == 7);
+    if (sh_dq) {
+        const int rc = mha_sh_dq(d, (g_variant == 6 || g_variant == 7) ? g_variant - 5 : 0, st);
+        if (rc != MMAE_OK) return rc;
+    } else
     if (head_dim == 64 && g_variant == 22) {                 // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
         d.max_tiles = (max_q_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);

@@ -58,4 +58,6 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
 bool mha_sh_applicable(const MhaDesc& d);
 int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st);
 bool mha_sh_dkdv_supported(const MhaDesc& d);
+bool mha_sh_dq_supported(const MhaDesc& d);
+int mha_sh_dq(const MhaDesc& d, int mode, hipStream_t st);
 int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st);   // needs workspace planes 1, 2 (see mha_bf16_bwd_dq_kernel)   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics

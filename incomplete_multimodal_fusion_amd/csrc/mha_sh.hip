@@ -116,7 +116,9 @@ __device__ __forceinline__ void sh_dma4(const float* base, int n, float* lds, in
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     float* ub = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, sh_uni(n * 4), 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds, 4, lane * 4, 0, 0, 0);
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds, 4, (lane + z) * 4, 0, 0, 0);
 }
 
 // transposed operand of the 32x32x16 products: element j of lane (r = lane & 31, hh = lane >> 5) is
@@ -777,6 +779,308 @@ __global__ __launch_bounds__(SD_W * 64) void mha_sh_dkdv_kernel(MhaDesc p, int h
     }
 }
 
+// ------------------------------------------------------------------------------------------------------ backward: dQ (+ row constants)
+// Query-stationary like the forward kernel: one 12-wave workgroup per sample walks its heads; waves 0-7 hold the "global"
+// queries of the pass (fusion chunk of 256 rows), waves 8-11 the "local" queries of the segment being swept (chunk of 128
+// rows); K/V tiles arrive once per (sample, head, pass) by LDS-DMA (ring of 3, loader = a rotating local wave).  Per
+// (32 queries x 64 keys):  S^T = K Q~^T and dP^T = V dO^T, each seeded through one extra k-step with the row constant split
+// into two bf16 terms (-lse2 = hi + lo to 2^-17: [1, 1] on the key side, [hi, lo] on the query side) so that only exp2 and one
+// multiply remain per score; dS^T = P^T o dP'^T; dQ^T += K^T dS^T with K^T read transposed from the same row-major image.
+// Padded keys are zero rows of the images (range check of the DMA): they produce finite P and contribute K^T dS = 0.
+// A slot's operands (Q, dO, and O for delta = rowsum(dO o O)) are staged by LDS-DMA in two steps one segment / pass ahead:
+// first O and dO -> delta, then Q into O's place (12 waves x 8 KB of staging + the ring fit the 160 KB of LDS; a third
+// buffer would not).  The kernel also writes the planes of the workspace the dK/dV kernel reads: delta, -lse2, -delta.
+#define SQ_NS 3
+#define SQ_D 2
+#define SQ_W 12
+#define SQ_MAXT 64
+#define SQ_MAXP 64
+
+__device__ __forceinline__ void sq_zero_rows(const MhaDesc& p, long row0, int n, int h, int tid) {
+    const long plane = (long)p.H * p.stat_stride;
+    for (int i = tid; i < n * 8; i += SQ_W * 64) {
+        const int rr = i >> 3, c = i & 7;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.dq) + (row0 + rr) * p.dq_stride + h * 64 + 8 * c) = u32x4{0u, 0u, 0u, 0u};
+        if (c == 0) {
+            const long at = (long)h * p.stat_stride + row0 + rr;
+            p.delta[at] = 0.f; p.delta[at + plane] = -p.lse[at] * SH_LOG2E; p.delta[at + 2 * plane] = 0.f;
+        }
+    }
+}
+// (hi, lo) bf16 split of x, packed for the query side of the seed k-step
+__device__ __forceinline__ unsigned sq_split(float x) {
+    const float hi = sh_bf16_round(x);
+    return sh_pack2(hi, x - hi);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SQ_W * 64) void mha_sh_dq_kernel(MhaDesc p, int hpb) {
+    __shared__ __attribute__((aligned(1024))) bf16 ringK[SQ_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 ringV[SQ_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 stA[SQ_W][32 * 64];       // wave-private: O rows, then Q rows
+    __shared__ __attribute__((aligned(1024))) bf16 stB[SQ_W][32 * 64];       // wave-private: dO rows
+    __shared__ __attribute__((aligned(256))) float stL[SQ_W][64];            // wave-private: lse of the slot's rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = sh_uni(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const bool local = wave >= 8;
+    const int qw = local ? wave - 8 : wave, CH = local ? 128 : 256;    // 32-query block of a 256-row (global) / 128-row (local) chunk
+    const int hgroups = p.H / hpb;
+    const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * hpb;
+    const int nseg = p.nseg, fus = nseg - 1;
+    ShSeg st; st.load(p, b, lane);
+    // tiles: first key row, n | seg << 8 | (first | last << 1) << 16.   passes: (global seg + 1) | chunk << 4 | has-local << 12 |
+    // segment mask of the tiles to sweep << 16 (a pass without global queries only sweeps the segments that still have local rows)
+    int tile_row = 0, tile_info = 0, pass_info = 0, ntile = 0, npass = 0;
+    {
+        int acc = 0;
+        for (int s = 0; s < nseg; ++s) {
+            const int L = st.kl(s), nt = (L + 63) >> 6, j = lane - acc;
+            if (j >= 0 && j < nt) { tile_row = st.ks(s) + 64 * j; tile_info = min(64, L - 64 * j) | (s << 8) | (((j == 0 ? 1 : 0) | (j == nt - 1 ? 2 : 0)) << 16); }
+            acc += nt;
+        }
+        ntile = min(acc, SQ_MAXT);
+        int nch = (st.ql(fus) + 255) >> 8, allmask = 0;
+        for (int s = 0; s < nseg; ++s) if (st.kl(s) > 0) allmask |= 1 << s;
+        for (int s = 0; s < fus; ++s) if (st.kl(s) > 0) nch = max(nch, (st.ql(s) + 127) >> 7);
+        nch = min(nch, SQ_MAXP);
+        if (lane < nch) {
+            int lmask = 0;
+            for (int s = 0; s < fus; ++s) if (st.kl(s) > 0 && st.ql(s) > 128 * lane) lmask |= 1 << s;
+            const int gs = 256 * lane < st.ql(fus) ? fus : -1;
+            pass_info = (gs + 1) | (lane << 4) | ((lmask != 0 ? 1 : 0) << 12) | ((gs >= 0 ? allmask : lmask) << 16);
+        }
+        npass = nch;
+    }
+    auto t_row = [&](int t) { return __builtin_amdgcn_readlane(tile_row, t); };
+    auto t_info = [&](int t) { return __builtin_amdgcn_readlane(tile_info, t); };
+    auto p_info = [&](int pi) { return __builtin_amdgcn_readlane(pass_info, pi); };
+    // rows whose gradient is zero by construction: no keys at all, an empty key segment (zeros or the uniform rows: dS = 0)
+    for (int hi = 0; hi < hpb; ++hi)
+        for (int s = 0; s < nseg; ++s) {
+            const int QL = st.ql(s);
+            if (QL > 0 && (ntile == 0 || (s < fus && st.kl(s) == 0))) sq_zero_rows(p, st.qs(s), QL, h0 + hi, tid);
+        }
+    if (ntile == 0 || npass == 0) return;
+    // first valid tile at or after t in pass pi (ntile: none)
+    auto seek = [&](int t, int pi) {
+        const int m = p_info(pi) >> 16;
+        while (t < ntile && !((m >> ((t_info(t) >> 8) & 15)) & 1)) ++t;
+        return t;
+    };
+    int G = 0;
+    for (int pi = 0; pi < npass; ++pi) { const int m = p_info(pi) >> 16; for (int t = 0; t < ntile; ++t) G += (m >> ((t_info(t) >> 8) & 15)) & 1; }
+    G *= hpb;
+
+    const bf16* qg = reinterpret_cast<const bf16*>(p.q);
+    const bf16* og = reinterpret_cast<const bf16*>(p.o);
+    const bf16* dog = reinterpret_cast<const bf16*>(p.dout);
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    const int qsb = (int)p.q_stride * 2, osb = (int)p.o_stride * 2, dosb = (int)p.do_stride * 2, ksb = (int)p.k_stride * 2, vsb = (int)p.v_stride * 2;
+    auto dma_voff = [&](int row_bytes, int z) { const int pr = (lane >> 3) + z; return pr * row_bytes + 16 * ((lane & 7) ^ sh_f(pr)); };
+    ShAddr ad; ad.init(lane);
+    const float cq = p.scale * SH_LOG2E;
+    int vm = 0, myseq = 0;
+    // ---- ring loader (rotating over the local-role waves)
+    int lt = 0, lp = 0, lh = 0, lj = 0, lstage = 0;
+    lt = seek(0, 0);
+    auto issue_ring = [&]() {
+        if (MODE != 2 && wave == 8 + (lj & 3)) {
+            const long row0 = t_row(lt); const int n = t_info(lt) & 255, h = h0 + lh;
+            int z = 0;
+            asm volatile("" : "+s"(z));
+            const int kv_ = dma_voff(ksb, z), vv_ = dma_voff(vsb, z);
+            const bf16* kb_ = kg + row0 * p.k_stride + h * 64;
+            const bf16* vb_ = vg + row0 * p.v_stride + h * 64;
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                sh_dma(kb_, n, ksb, kv_ ^ (16 * (pc & 1)), 8 * pc * ksb, &ringK[lstage][pc * 512]);
+                sh_dma(vb_, n, vsb, vv_ ^ (16 * (pc & 1)), 8 * pc * vsb, &ringV[lstage][pc * 512]);
+            }
+            vm += 16; myseq = vm;
+        }
+        ++lj;
+        if (++lstage == SQ_NS) lstage = 0;
+        lt = seek(lt + 1, lp);
+        while (lt >= ntile && lh < hpb) { if (++lp == npass) { lp = 0; ++lh; } if (lh < hpb) lt = seek(0, lp); }
+    };
+    auto rows_of = [&](int s, int chunk) { return min(32, st.ql(s) - CH * chunk - 32 * qw); };
+    // this wave's next target (head, pass, segment)
+    int nh = -1, np_ = 0, nsg = 0;
+    auto find_next = [&](int hi, int pi, int s0) {
+        nh = -1;
+        for (; hi < hpb; ++hi, pi = 0, s0 = 0)
+            for (; pi < npass; ++pi, s0 = 0) {
+                const int pinf = p_info(pi), c = (pinf >> 4) & 255;
+                if (!local) {
+                    const int gs = (pinf & 15) - 1;
+                    if (gs >= 0 && rows_of(gs, c) > 0) { nh = hi; np_ = pi; nsg = gs; return; }
+                } else {
+                    if (!((pinf >> 12) & 1)) continue;
+                    for (int s = s0; s < fus; ++s)
+                        if (st.kl(s) > 0 && rows_of(s, c) > 0) { nh = hi; np_ = pi; nsg = s; return; }
+                }
+            }
+    };
+    auto chunk_of = [&](int pi) { return (p_info(pi) >> 4) & 255; };
+    // two-step operand prefetch of the next target: (1) O -> stA, dO -> stB, lse -> stL; (2) delta from (1), then Q -> stA
+    int pf = 0, mark1 = 0, mark2 = 0, pf_iter = 0;
+    float delta_next = 0.f;
+    auto row0_of = [&](int s, int chunk) { return (long)st.qs(s) + CH * chunk + 32 * qw; };
+    auto issue_stage1 = [&](int g) {
+        const int c = chunk_of(np_), nq = rows_of(nsg, c), h = h0 + nh;
+        const long row0 = row0_of(nsg, c);
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const int ov = dma_voff(osb, z), dv_ = dma_voff(dosb, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sh_dma(og + row0 * p.o_stride + h * 64, nq, osb, ov ^ (16 * (j & 1)), 8 * j * osb, &stA[wave][8 * j * 64]);
+            sh_dma(dog + row0 * p.do_stride + h * 64, nq, dosb, dv_ ^ (16 * (j & 1)), 8 * j * dosb, &stB[wave][8 * j * 64]);
+        }
+        sh_dma4(p.lse + (long)h * p.stat_stride + row0, nq, &stL[wave][0], lane);
+        vm += 9; mark1 = vm; pf = 1; pf_iter = g;
+    };
+    auto do_stage2 = [&]() {
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        sh_wait_vm(vm - mark1);
+        const int base = ad.krow0 + z;
+        float dpart = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 o8 = sh_ld8(&stA[wave][0] + (base ^ (16 * ks))), d8 = sh_ld8(&stB[wave][0] + (base ^ (16 * ks)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dpart += (float)o8[j] * (float)d8[j];
+        }
+        delta_next = sh_swap_sum(dpart);
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = chunk_of(np_), nq = rows_of(nsg, c), h = h0 + nh;
+        const long row0 = row0_of(nsg, c);
+        const int qv = dma_voff(qsb, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh_dma(qg + row0 * p.q_stride + h * 64, nq, qsb, qv ^ (16 * (j & 1)), 8 * j * qsb, &stA[wave][8 * j * 64]);
+        vm += 4; mark2 = vm; pf = 2;
+    };
+
+    bf16x8 q[4], dO[4];
+    f32x16 dq[2];
+    unsigned extS = 0, extD = 0;
+    int my_row = 0, my_nq = 0;
+
+    // ---- prologue
+    find_next(0, 0, 0);
+    if (nh >= 0) issue_stage1(-1);
+    for (int i = 0; i < SQ_D && i < G; ++i) issue_ring();
+
+    bool act = false;
+    int t = seek(0, 0), pi = 0, hi = 0, stage = 0;
+    for (int g = 0; g < G; ++g) {
+        if (wave == 8 + (g & 3)) sh_wait_vm(vm - myseq);
+        __builtin_amdgcn_s_barrier();
+        if (lj < G) issue_ring();
+        const int tinf = t_info(t), sg = (tinf >> 8) & 255, fl = tinf >> 16;
+        const int h = h0 + hi;
+        const bool first_of_pass = t == seek(0, pi);
+        if (nh == hi && np_ == pi && (local ? ((fl & 1) && nsg == sg) : first_of_pass)) {       // slot switch
+            if (pf == 1) do_stage2();
+            int z = 0;
+            asm volatile("" : "+s"(z));
+            sh_wait_vm(vm - mark2);
+            const int c = chunk_of(pi);
+            my_nq = rows_of(nsg, c);
+            my_row = (int)row0_of(nsg, c) + z + r;
+            const int base = ad.krow0 + z;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 raw = sh_ld8(&stA[wave][0] + (base ^ (16 * ks)));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[ks][j] = (bf16)((float)raw[j] * cq);
+                dO[ks] = sh_ld8(&stB[wave][0] + (base ^ (16 * ks)));
+            }
+            const float lse2 = stL[wave][r] * SH_LOG2E, delta = delta_next;
+            extS = hh == 0 ? sq_split(-lse2) : 0u;
+            extD = hh == 0 ? sq_split(-delta) : 0u;
+            if (r < my_nq && hh == 0) {                            // the row constants the dK/dV kernel reads
+                const long at = (long)h * p.stat_stride + my_row, plane = (long)p.H * p.stat_stride;
+                p.delta[at] = delta; p.delta[at + plane] = -lse2; p.delta[at + 2 * plane] = -delta;
+            }
+            vm += 3;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+            act = true; pf = 0;
+            __builtin_amdgcn_sched_barrier(0);
+            if (local) find_next(hi, pi, sg + 1); else find_next(hi, pi + 1, 0);
+            if (nh >= 0) issue_stage1(g);
+        } else if (pf == 1 && g > pf_iter) {
+            do_stage2();
+        }
+        if (act) {
+            if (MODE != 1) {
+                const bf16* Kst = ringK[0]; const bf16* Vst = ringV[0];
+                const int sel = stage * 4096, kbase = ad.krow0 + sel, vbase = ad.tr00 + sel;
+                int zc = 0;                                        // (opaque zero: keeps the constant operand out of the loop-invariant set,
+                asm volatile("" : "+s"(zc));                       //  where it was spilled and reloaded from scratch every tile)
+                const bf16x8 kone = sh_ext((hh == 0 ? 0x3f803f80u : 0u) | (unsigned)zc), qeS = sh_ext(extS), qeD = sh_ext(extD);
+                f32x16 z16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z16[i] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 pb[2], dsb[2];
+                    {
+                        f32x16 sacc = sh_mma(kone, qeS, z16);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) sacc = sh_mma(sh_ld8(Kst + 2048 * kb + (kbase ^ (16 * ks))), q[ks], sacc);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) pb[s2][j] = (bf16)sh_exp2(sacc[8 * s2 + j]);
+                    }
+                    {
+                        f32x16 dpacc = sh_mma(kone, qeD, z16);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dpacc = sh_mma(sh_ld8(Vst + 2048 * kb + (kbase ^ (16 * ks))), dO[ks], dpacc);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) dsb[s2][j] = (bf16)((float)pb[s2][j] * dpacc[8 * s2 + j]);
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16* kb_ = Kst + 64 * (32 * kb + 16 * s2);
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) dq[d] = sh_mma(sh_tr(kb_, vbase ^ (32 * d), vbase ^ (32 * d + 520)), dsb[s2], dq[d]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // last tile of the slot: a local wave's segment ends, a global wave's pass ends
+            const int tn = seek(t + 1, pi);
+            if (local ? (fl & 2) != 0 : tn >= ntile) {
+                const bool valid = r < my_nq;
+                bf16* dqp = reinterpret_cast<bf16*>(p.dq) + (long)my_row * p.dq_stride + h * 64 + 8 * hh;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        unsigned a0 = sh_pack2(dq[d][4 * i] * p.scale, dq[d][4 * i + 1] * p.scale), a1 = sh_pack2(dq[d][4 * i + 2] * p.scale, dq[d][4 * i + 3] * p.scale);
+                        unsigned b0 = sh_pack2(dq[d][4 * i + 4] * p.scale, dq[d][4 * i + 5] * p.scale), b1 = sh_pack2(dq[d][4 * i + 6] * p.scale, dq[d][4 * i + 7] * p.scale);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+                        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+                        if (valid) *reinterpret_cast<u32x4*>(dqp + 32 * d + 8 * i) = u32x4{a0, a1, b0, b1};
+                    }
+                act = false; vm += 4;
+            }
+        }
+        if (++stage == SQ_NS) stage = 0;
+        t = seek(t + 1, pi);
+        while (t >= ntile && hi < hpb) { if (++pi == npass) { pi = 0; ++hi; } if (hi < hpb) t = seek(0, pi); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ host side
 static int sh_heads_per_block(int B, int H) {
     // one workgroup per CU when the batch allows it: a block walks `hpb` heads of its sample (hpb divides H)
@@ -820,6 +1124,22 @@ int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st) {
     if (mode == 1) MMAE_LAUNCH(mha_sh_dkdv_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_dkdv_kernel<2>, grid, blk, 0, st, d, hpb);
     else MMAE_LAUNCH(mha_sh_dkdv_kernel<0>, grid, blk, 0, st, d, hpb);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+// query-stationary dQ (mha_sh_dq_kernel); also produces the workspace planes (delta, -lse2, -delta)
+bool mha_sh_dq_supported(const MhaDesc& d) {
+    return d.max_k_rows / 64 + d.nseg <= SQ_MAXT && d.nseg <= MAXSEG && d.max_q_rows / 128 + 1 <= SQ_MAXP;
+}
+
+int mha_sh_dq(const MhaDesc& d, int mode, hipStream_t st) {
+    if (!mha_sh_dq_supported(d)) return MMAE_ERR_ARG;
+    const int hpb = sh_heads_per_block(d.B, d.H);
+    const dim3 grid(d.B * (d.H / hpb)), blk(SQ_W * 64);
+    if (mode == 1) MMAE_LAUNCH(mha_sh_dq_kernel<1>, grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH(mha_sh_dq_kernel<2>, grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH(mha_sh_dq_kernel<0>, grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
