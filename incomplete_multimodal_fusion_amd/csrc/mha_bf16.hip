@@ -77,7 +77,11 @@ template <int DH, int NT = 256> struct Geo {
     // conflict-free.  The former 144 B pitch (DH + 8) made both kinds of read 2-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
     // was 36-41 % in all three kernels, with the LDS array 54-57 % busy in the backward ones (now 0 % / 33-37 %; the kernel
     // times did not move: the LDS array was not what they wait for, see the forward kernel's notes on block start-up latency).
-    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH == 64 ? 80 : DH + 8, CPR = DH / 8, NCH = 64 * CPR / NT;
+    // DH 32 (the decoders' 8 heads x 32): 96 B.  Slots s = (6 * row + chunk) mod 16 are distinct over a b128 lane group (rows 0-3 /
+    // 12-15 of chunk g: {0,6,12,2,8,14,4,10}, rows 4-11 of chunk g+1: {9,15,5,11,1,7,13,3}), and the 8 rows x 32 B of a
+    // transposed read start at banks 24 * row mod 64 = {0,24,48,8,32,56,16,40}.  The 80 B pitch (DH + 8) left 40-48 % of the LDS
+    // cycles of the three DH-32 kernels conflicted (profiles/r02_sq_step.md).
+    static constexpr int KS = DH / 32, DT = DH / 16, KP = DH == 64 ? 80 : 48, CPR = DH / 8, NCH = 64 * CPR / NT;
 };
 
 // global -> registers: this thread's chunks of a [<=64 rows][DH] tile (rows >= n zero-filled)

@@ -121,6 +121,8 @@ class MultiMAE(nn.Module):
         self.per_sample_masks = False      # True: every sample draws / uses its own mask row (packed superset)
         self.fuse_unpatchify_loss = False  # True: preds are PredTokens (fused unpatchify + masked loss)
         self.check_masks = True            # explicit task_masks: verify kept count == num_encoded_tokens (host sync)
+        self.decoder_streams = os.environ.get("MMAE_DECODER_STREAMS", "0") == "1"   # True: the per-modality decoders run on separate HIP streams
+        self._dec_streams = []
         self.side_stream_wgrad = False     # True: encoder weight-gradient GEMMs overlap the backward chain on a side
                                            # stream; the trainer must ops.join_wgrad_stream() before reading .grad
 
@@ -399,15 +401,33 @@ class MultiMAE(nn.Module):
         dec_seg = ops.Segments.dense(B, P, device)
         enc_rows = tokens_T[BN:]
         preds = {}
-        for d, adapter in self.output_adapters.items():
-            # fp32 adapters (:518-527) take the final norm's fp32 output itself, as the reference's do (layer_norm leaves an
-            # autocast region in fp32) -- not the bf16 copy widened again
-            rows = tokens[BN:] if d in fp32_output_adapters else enc_rows
-            with torch.autocast("cuda", enabled=False) if d in fp32_output_adapters else _nullctx():
-                tk = adapter.forward_tokens(rows, B, P, dec_seg, once=True)
+        # The decoders are independent chains of SMALL kernels (B*P rows x 256 columns: a GEMM of 256 tiles, one per CU, no second
+        # wave to hide its tail).  decoder_streams runs them side by side on their own HIP streams (autograd replays each
+        # chain's backward on the stream its forward ran on), joined before the losses.
+        main = torch.cuda.current_stream()
+        use_streams = self.decoder_streams and len(self.output_adapters) > 1 and enc_rows.is_cuda
+        if use_streams:
+            while len(self._dec_streams) < len(self.output_adapters) - 1:
+                self._dec_streams.append(torch.cuda.Stream(device=enc_rows.device))
+        for i, (d, adapter) in enumerate(self.output_adapters.items()):
+            st_ = self._dec_streams[i - 1] if (use_streams and i > 0) else main
+            if st_ is not main:
+                st_.wait_stream(main)
+            with torch.cuda.stream(st_):
+                # fp32 adapters (:518-527) take the final norm's fp32 output itself, as the reference's do (layer_norm leaves an
+                # autocast region in fp32) -- not the bf16 copy widened again
+                rows = tokens[BN:] if d in fp32_output_adapters else enc_rows
+                with torch.autocast("cuda", enabled=False) if d in fp32_output_adapters else _nullctx():
+                    tk = adapter.forward_tokens(rows, B, P, dec_seg, once=True)
+                if st_ is not main:
+                    rows.record_stream(st_)
+                    tk.record_stream(main)
             C = adapter.num_channels
             preds[d] = PredTokens(tk, B, C, H, W, adapter.P_H) if self.fuse_unpatchify_loss else \
                 ops.unpatchify(tk, B, C, H, W, adapter.P_H)
+        if use_streams:
+            for st_ in self._dec_streams[:len(self.output_adapters) - 1]:
+                main.wait_stream(st_)
 
         if not self.has_contrastive_tokens:
             return (preds, task_masks, return_tokens, ori_tokens, enc_fus)                  # multimae_quadruplet.py:490

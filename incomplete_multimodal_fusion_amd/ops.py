@@ -315,9 +315,10 @@ class _MHA(torch.autograd.Function):
             raise _lib.MmaeLibraryError("masked attention: at most 80 64-row tiles (~4.8k rows) per sample in one call "
                                         "(MAXT in csrc/mha_bf16.hip); got %d query / %d key rows" % (qseg.max_rows, kseg.max_rows))
         es = qt.element_size()
-        # bench.py's roofline_attention: every launch of the dh = 64 instance (encoder blocks, pooling), so the event
-        # average is the same population as that kernel's row in the rocprofv3 summary
-        timed = _TIMER is not None and _TIMER.name == "mmae_mha_fwd" and dh == 64
+        # bench.py's roofline_attention: every launch that the library routes to the sample-head forward kernel (encoder
+        # blocks: >= 128 rows per sample; the few-query pooling calls run the tile-per-block kernel), so the event average
+        # is the same population as mha_sh_fwd_kernel's row in the rocprofv3 summary
+        timed = _TIMER is not None and _TIMER.name == "mmae_mha_fwd" and dh == 64 and qseg.max_rows >= 128 and kseg.max_rows >= 128
         if timed:
             ql, kl = qseg.length.long(), kseg.length.long()
             pairs = (ql[:, :-1] * kl[:, :-1]).sum() + (ql[:, -1] * kl.sum(1)).sum()     # mask-aware (q, k) pairs
