@@ -161,10 +161,11 @@ int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* 
  * no optimizer step when norm >= skip_grad; torch GradScaler: no step on a non-finite gradient) without the host round trip.
  * mmae_adamw_control reads the norm mmae_grad_norm left on the device and fills ctl4 (4 floats, zero-initialised once by the
  * caller): [0] gradient multiplier = grad_scale * min(1, max_norm / (norm*|grad_scale| + 1e-6)) (max_norm 0: no clipping),
- * [1] 1 when the step is skipped (norm non-finite, or skip_norm > 0 and norm >= skip_norm), [2] running count of skipped
+ * [1] 1 when the step is skipped (norm non-finite and check_finite, or skip_norm > 0 and norm >= skip_norm), [2] running count of skipped
  * steps, [3] the unscaled norm.  mmae_adamw_step_ctl is mmae_adamw_step taking the multiplier / skip flag from ctl4 and
  * bias-correcting with step - ctl4[2], i.e. exactly as if optimizer.step() had not been called for skipped steps. */
-int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, float* ctl4, void* stream);
+int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, int check_finite,
+                       float* ctl4, void* stream);
 int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, const float* ctl4, void* stream);
 int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);

@@ -305,8 +305,11 @@ __global__ __launch_bounds__(256) void masked_ce_partial_kernel(CEDesc d) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            // a target outside [0, C) -- F.cross_entropy's ignore_index (-100) in particular -- contributes no loss (and no
+            // gradient below), as reduction='none' gives 0 for an ignored pixel; it used to be read as "logit 0"
+            const bool valid = tp[j] >= 0 && tp[j] < (long long)d.C;
             const float lse = mx[j] + __logf(se[j]);
-            acc += (1.f - d.smooth) * (lse - xt[j]) + d.smooth * (lse - sx[j] / (float)d.C);
+            acc += valid ? (1.f - d.smooth) * (lse - xt[j]) + d.smooth * (lse - sx[j] / (float)d.C) : 0.f;
         }
     }
     acc = wave_sum(acc);
@@ -345,8 +348,10 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(CEDesc d, const floa
             if (coef != 0.f) {
                 const f32x4 v = ce_logits4<T, TOKENS>(d, r, b, c, pix, py, px);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    g[j] = coef * (__expf(v[j] - mx[j]) / se[j] - ((long long)c == tp[j] ? 1.f - d.smooth : 0.f) - d.smooth / (float)d.C);
+                for (int j = 0; j < 4; ++j) {
+                    const bool valid = tp[j] >= 0 && tp[j] < (long long)d.C;
+                    g[j] = valid ? coef * (__expf(v[j] - mx[j]) / se[j] - ((long long)c == tp[j] ? 1.f - d.smooth : 0.f) - d.smooth / (float)d.C) : 0.f;
+                }
             }
             if (TOKENS) st4<T>(reinterpret_cast<T*>(gpred) + r * ((long)d.C * ps2) + (long)c * ps2 + pix, g);
             else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(gpred) + (((long)b * d.C + c) * d.H + py + y) * d.W + px + x) = g;

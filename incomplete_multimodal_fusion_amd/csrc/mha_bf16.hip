@@ -719,7 +719,10 @@ template <int PITCH> struct Stage64 {
 // [3] iterations, [4] kernel entry -> first iteration, [5] 1 per wave with work, [6] entry -> segment table in registers,
 // [7] -> Q rows and first K/V tile arrived.  One row per wave, plain stores (same-address atomics of 41k waves serialise for
 // milliseconds and distort everything they time); mmae_debug_mha_stamps() sums and clears them.
-#define STAMP_WAVES 131072
+#ifndef MMAE_DIAG
+#define MMAE_DIAG 1
+#endif
+#define STAMP_WAVES (MMAE_DIAG ? 131072 : 1)
 __device__ unsigned long long g_mha_stamps[STAMP_WAVES][8];
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -727,7 +730,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 extern "C" int mmae_debug_mha_stamps(unsigned long long* host8) {
-    if (!host8) return MMAE_ERR_ARG;
+    if (!host8 || !MMAE_DIAG) return MMAE_ERR_ARG;
     static unsigned long long* h = nullptr;
     if (!h) h = new unsigned long long[(size_t)STAMP_WAVES * 8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mha_stamps), sizeof(unsigned long long) * STAMP_WAVES * 8) != hipSuccess) return MMAE_ERR_LAUNCH;
@@ -973,7 +976,13 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
         e.max_tiles = g_variant == 4 ? (d.max_tiles + 3) / 4 + d.nseg : (d.max_tiles + 1) / 2 + d.nseg;
         const dim3 grid(xcd_grid(e.B, e.H, e.max_tiles)), blk(256);
         if (g_variant == 4) MMAE_LAUNCH((mha_bf16_fwd32_kernel<2>), grid, blk, 0, st, e);
-        else if (g_variant == 9) MMAE_LAUNCH((mha_bf16_fwd32_kernel<1, true>), grid, blk, 0, st, e);
+        else if (g_variant == 9) {
+#if MMAE_DIAG
+            MMAE_LAUNCH((mha_bf16_fwd32_kernel<1, true>), grid, blk, 0, st, e);
+#else
+            return MMAE_ERR_ARG;
+#endif
+        }
         else MMAE_LAUNCH((mha_bf16_fwd32_kernel<1>), grid, blk, 0, st, e);
     } else if (head_dim == 64 && g_variant == 2) {           // round-1 kernel: 16x16x32, 4 waves x 32 queries = 128-query tiles
         MhaDesc e = d; e.max_tiles = (d.max_tiles + 1) / 2 + d.nseg;

@@ -165,7 +165,10 @@ struct ShSlot {
 //   [0] vmcnt wait at the top  [1] barrier  [2] ring issue + tile record  [3] slot switch  [4] QK^T  [5] softmax  [6] PV
 //   [7] finish (stores)  [8] whole loop  [9] units (slot-steps)  [10] iterations  [11] waves
 //   slot switch in detail: [12] wait for the staged Q  [13] LDS reads + conversion  [14] next-target scan  (the rest of [3] is the Q DMA issue)
-#define SH_STAMP_WAVES 8192
+#ifndef MMAE_DIAG
+#define MMAE_DIAG 1
+#endif
+#define SH_STAMP_WAVES (MMAE_DIAG ? 8192 : 1)
 __device__ unsigned long long g_sh_stamps[SH_STAMP_WAVES][16];
 __device__ __forceinline__ unsigned long long sh_now() {
     unsigned long long t;
@@ -173,7 +176,7 @@ __device__ __forceinline__ unsigned long long sh_now() {
     return t;
 }
 extern "C" int mmae_debug_sh_stamps(unsigned long long* host32) {
-    if (!host32) return MMAE_ERR_ARG;
+    if (!host32 || !MMAE_DIAG) return MMAE_ERR_ARG;
     static unsigned long long* h = nullptr;
     if (!h) h = new unsigned long long[(size_t)SH_STAMP_WAVES * 16];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sh_stamps), sizeof(unsigned long long) * SH_STAMP_WAVES * 16) != hipSuccess) return MMAE_ERR_LAUNCH;
@@ -1104,7 +1107,11 @@ int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
     const dim3 grid(d.B * (d.H / hpb)), blk(1024);
     if (mode == 1) MMAE_LAUNCH(mha_sh_fwd_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_fwd_kernel<2>, grid, blk, 0, st, d, hpb);
+#if MMAE_DIAG
     else if (mode == 3) MMAE_LAUNCH(mha_sh_fwd_kernel<3>, grid, blk, 0, st, d, hpb);
+#else
+    else if (mode == 3) return MMAE_ERR_ARG;
+#endif
     else MMAE_LAUNCH(mha_sh_fwd_kernel<0>, grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;

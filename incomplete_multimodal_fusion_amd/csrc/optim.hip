@@ -14,11 +14,13 @@
 // this step must not be taken, ctl[2] = number of steps skipped so far (the bias correction uses step - ctl[2], exactly as if
 // optimizer.step() had not been called), ctl[3] = the unscaled gradient norm.
 __global__ void adamw_control_kernel(const float* __restrict__ norm, float max_norm, float skip_norm, float grad_scale,
-                                     float* __restrict__ ctl) {
+                                     int guard, float* __restrict__ ctl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // guard: skip the step when the norm is inf / NaN (FlatAdamW.step(check_finite=...)).  The caller passes skip_norm = 0
+    // together with a clip norm: native_scaler.py:24-32 is `if clip_grad ... elif skip_grad`.
     const float nrm = norm[0] * fabsf(grad_scale);
     const bool finite = (nrm == nrm) && (nrm <= 3.0e38f);
-    const bool skip = !finite || (skip_norm > 0.f && nrm >= skip_norm);
+    const bool skip = (guard && !finite) || (skip_norm > 0.f && nrm >= skip_norm);
     float coef = 1.f;
     if (max_norm > 0.f) { coef = max_norm / (nrm + 1e-6f); coef = coef > 1.f ? 1.f : coef; }   // torch clip_grad_norm_
     ctl[0] = skip ? 0.f : grad_scale * coef;
@@ -164,11 +166,11 @@ extern "C" int mmae_adamw_step(long n, float* p, const float* g, float* m, float
     return adamw_launch(n, p, g, m, v, shadow_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
 }
 
-extern "C" int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, float* ctl4,
-                                  void* stream) {
+extern "C" int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale,
+                                  int check_finite, float* ctl4, void* stream) {
     if (!grad_norm || !ctl4 || max_norm < 0.f || skip_norm < 0.f) return MMAE_ERR_ARG;
     MMAE_LAUNCH(adamw_control_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), grad_norm, max_norm,
-                       skip_norm, grad_scale, ctl4);
+                       skip_norm, grad_scale, check_finite, ctl4);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

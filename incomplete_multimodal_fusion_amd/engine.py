@@ -48,6 +48,7 @@ class FlatAdamW:
         self._ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self._norm = torch.empty(1, dtype=torch.float32, device=dev)
         self._ctl = torch.zeros(4, dtype=torch.float32, device=dev)     # mmae_adamw_control: multiplier, skip, #skipped, norm
+        self._ctl_used = False
         self._pstep: Dict[int, int] = {id(p): 0 for p in self.params}    # per-parameter step counts, as torch keeps them
         self._in_place = set()             # ids of weights whose gradient a producer wrote in place since zero_grad()
         with torch.no_grad():
@@ -179,9 +180,18 @@ class FlatAdamW:
         self.flush()
         self.steps += 1
         ctl = clip_grad is not None or skip_grad is not None or check_finite
+        if not ctl and self._ctl_used:
+            # once a controlled step has run, the device holds the count of skipped steps the bias correction needs: an
+            # uncontrolled step afterwards goes through the same kernel (no threshold, no guard) instead of using a host count
+            # that may be too high by the skipped steps
+            ctl = True
         if ctl:
+            self._ctl_used = True
             call("mmae_grad_norm", self.n, ptr(self.grads), ptr(self._ws), ptr(self._norm), stream())
-            call("mmae_adamw_control", ptr(self._norm), float(clip_grad or 0.0), float(skip_grad or 0.0), float(grad_scale),
+            # the reference clips OR skips (native_scaler.py:24-32: `if clip_grad ... elif skip_grad`): with a clip norm the skip
+            # threshold is not applied; the non-finite guard follows check_finite
+            thr = 0.0 if clip_grad is not None else float(skip_grad or 0.0)
+            call("mmae_adamw_control", ptr(self._norm), float(clip_grad or 0.0), thr, float(grad_scale), 1 if check_finite else 0,
                  ptr(self._ctl), stream())
         lr = float(g["lr"]) * float(g.get("lr_scale", 1.0))
         for o, n, st in self._update_ranges():
