@@ -222,6 +222,166 @@ __global__ __launch_bounds__(256) void modattn_bwd_finish_kernel(ModAttn p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ fast paths (I == 512, NS slots)
+// The generic kernels test `s < p.ns` and `col < I` around every access; each test became a branch with an s_waitcnt vmcnt(0)
+// behind it, so the 2 * ns + 1 row pieces of a (sample, patch) were fetched one after the other.  Same arithmetic here with
+// the slot count as a template parameter and one 512-column chunk: the slot rows come from scalar loads, every K / V piece is
+// requested before the first one is used, head sums run on DPP.
+template <int CTRL> __device__ __forceinline__ float ma_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int DH> __device__ __forceinline__ float head_sum_v(float v) {
+    v += ma_dpp<0xB1>(v);                      // quad_perm [1,0,3,2]
+    v += ma_dpp<0x4E>(v);                      // quad_perm [2,3,0,1]
+    if (DH == 64) v += ma_dpp<0x141>(v);       // row_half_mirror: lane i <-> 7 - i of its group of 8
+    return v;
+}
+template <typename T> __device__ __forceinline__ void cvt8(const typename Vec8<T>::type& r, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = to_f(r[j]);
+}
+
+template <typename T, int DH, int NS>
+__global__ __launch_bounds__(256) void modattn_fwd_fast_kernel(ModAttn p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int col = 8 * lane;
+    const T* kv = reinterpret_cast<const T*>(p.kv);
+    int srow[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) srow[s] = __builtin_amdgcn_readfirstlane(p.slot_row[row * NS + s]);
+    typename Vec8<T>::type qr, kr[NS], vr[NS];
+    qr = ld8<T>(reinterpret_cast<const T*>(p.q) + row * p.q_stride + col);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kr[s] = ld8<T>(kv + (long)srow[s] * p.kv_stride + col);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vr[s] = ld8<T>(kv + (long)srow[s] * p.kv_stride + 512 + col);
+    __builtin_amdgcn_sched_barrier(0);
+    float q8[8], sc[NS];
+    cvt8<T>(qr, q8);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float k8[8], d = 0.f;
+        cvt8<T>(kr[s], k8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += q8[j] * k8[j];
+        sc[s] = head_sum_v<DH>(d) * p.scale;
+        mx = fmaxf(mx, sc[s]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { sc[s] = __expf(sc[s] - mx); den += sc[s]; }
+    const float inv = 1.f / den;
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float v8[8];
+        cvt8<T>(vr[s], v8);
+        const float w = sc[s] * inv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] += w * v8[j];
+    }
+    st8f<T>(reinterpret_cast<T*>(p.out) + row * p.out_stride + col, o8);
+}
+
+template <typename T, int DH, int NS>
+__global__ __launch_bounds__(256) void modattn_bwd_fast_kernel(ModAttn p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 1024];  // [4][2 * I]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pp = blockIdx.x;                                     // patch
+    const int sp = blockIdx.y;                                     // sample group: b = sp*4 + wave, step 4*nsplit
+    const T* kv = reinterpret_cast<const T*>(p.kv);
+    T* dkv = reinterpret_cast<T*>(p.dkv);
+    const int col = 8 * lane;
+    float accK[8], accV[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accK[j] = 0.f; accV[j] = 0.f; }
+    for (int b = sp * 4 + wave; b < p.B; b += 4 * p.nsplit) {
+        const long row = (long)b * p.P + pp;
+        int srow[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) srow[s] = __builtin_amdgcn_readfirstlane(p.slot_row[row * NS + s]);
+        typename Vec8<T>::type qr, gr, kr[NS], vr[NS];
+        qr = ld8<T>(reinterpret_cast<const T*>(p.q) + row * p.q_stride + col);
+        gr = ld8<T>(reinterpret_cast<const T*>(p.dout) + row * p.do_stride + col);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kr[s] = ld8<T>(kv + (long)srow[s] * p.kv_stride + col);
+            vr[s] = ld8<T>(kv + (long)srow[s] * p.kv_stride + 512 + col);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float q8[8], g8[8], sc[NS], dp[NS];
+        cvt8<T>(qr, q8); cvt8<T>(gr, g8);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float k8[8], v8[8], d = 0.f, e = 0.f;
+            cvt8<T>(kr[s], k8); cvt8<T>(vr[s], v8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { d += q8[j] * k8[j]; e += g8[j] * v8[j]; }
+            sc[s] = head_sum_v<DH>(d) * p.scale;
+            dp[s] = head_sum_v<DH>(e);
+            mx = fmaxf(mx, sc[s]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { sc[s] = __expf(sc[s] - mx); den += sc[s]; }
+        const float inv = 1.f / den;
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { sc[s] *= inv; dot += sc[s] * dp[s]; }
+        float dq8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dq8[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float ds = sc[s] * (dp[s] - dot) * p.scale;
+            float k8[8], dk8[8], dv8[8];
+            cvt8<T>(kr[s], k8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dq8[j] += ds * k8[j]; dk8[j] = ds * q8[j]; dv8[j] = sc[s] * g8[j]; }
+            if (srow[s] < p.shared_base) {                          // wave-uniform
+                st8f<T>(dkv + (long)srow[s] * p.dkv_stride + col, dk8);
+                st8f<T>(dkv + (long)srow[s] * p.dkv_stride + 512 + col, dv8);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { accK[j] += dk8[j]; accV[j] += dv8[j]; }
+            }
+        }
+        st8f<T>(reinterpret_cast<T*>(p.dq) + row * p.dq_stride + col, dq8);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[wave * 1024 + col + j] = accK[j]; red[wave * 1024 + 512 + col + j] = accV[j]; }
+    __syncthreads();
+    float* wrow = p.ws + ((long)sp * p.P + pp) * 1024;
+    for (int c = threadIdx.x; c < 1024; c += 256) wrow[c] = red[c] + red[1024 + c] + red[2048 + c] + red[3072 + c];
+}
+
+template <typename T, int DH>
+static bool modattn_fwd_fast(const ModAttn& p, dim3 grid, hipStream_t st) {
+    switch (p.ns) {
+        case 2: MMAE_LAUNCH((modattn_fwd_fast_kernel<T, DH, 2>), grid, dim3(256), 0, st, p); return true;
+        case 3: MMAE_LAUNCH((modattn_fwd_fast_kernel<T, DH, 3>), grid, dim3(256), 0, st, p); return true;
+        case 4: MMAE_LAUNCH((modattn_fwd_fast_kernel<T, DH, 4>), grid, dim3(256), 0, st, p); return true;
+        case 5: MMAE_LAUNCH((modattn_fwd_fast_kernel<T, DH, 5>), grid, dim3(256), 0, st, p); return true;
+        default: return false;
+    }
+}
+template <typename T, int DH>
+static bool modattn_bwd_fast(const ModAttn& p, dim3 grid, hipStream_t st) {
+    switch (p.ns) {
+        case 2: MMAE_LAUNCH((modattn_bwd_fast_kernel<T, DH, 2>), grid, dim3(256), 0, st, p); return true;
+        case 3: MMAE_LAUNCH((modattn_bwd_fast_kernel<T, DH, 3>), grid, dim3(256), 0, st, p); return true;
+        case 4: MMAE_LAUNCH((modattn_bwd_fast_kernel<T, DH, 4>), grid, dim3(256), 0, st, p); return true;
+        case 5: MMAE_LAUNCH((modattn_bwd_fast_kernel<T, DH, 5>), grid, dim3(256), 0, st, p); return true;
+        default: return false;
+    }
+}
+
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int ma_check(int dtype, int head_dim, int B, int P, int ns, int I, long a, long b, long c) {
@@ -243,6 +403,11 @@ extern "C" int mmae_modattn_fwd(int dtype, int head_dim, int B, int P, int ns, i
     p.out_stride = out_stride; p.rows = (long)B * P; p.I = inner; p.ns = ns; p.P = P; p.B = B; p.scale = scale;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(p.rows, 4)), blk(256);
+    if (inner == 512 && ns >= 2 && ns <= 5) {
+        const bool ok = dtype == MMAE_BF16 ? (head_dim == 64 ? modattn_fwd_fast<bf16, 64>(p, grid, st) : modattn_fwd_fast<bf16, 32>(p, grid, st))
+                                           : (head_dim == 64 ? modattn_fwd_fast<float, 64>(p, grid, st) : modattn_fwd_fast<float, 32>(p, grid, st));
+        if (ok) { MMAE_CHECK_LAUNCH(); return MMAE_OK; }
+    }
     if (dtype == MMAE_BF16) {
         if (head_dim == 64) MMAE_LAUNCH((modattn_fwd_kernel<bf16, 64>), grid, blk, 0, st, p);
         else MMAE_LAUNCH((modattn_fwd_kernel<bf16, 32>), grid, blk, 0, st, p);
@@ -275,7 +440,12 @@ extern "C" int mmae_modattn_bwd(int dtype, int head_dim, int B, int P, int ns, i
     const size_t lds = (size_t)4 * 2 * inner * sizeof(float);
     const bool two = inner > 512;
 #define GO(T, DHV, NCHV) MMAE_LAUNCH((modattn_bwd_kernel<T, DHV, NCHV>), grid, blk, lds, st, p)
-    if (dtype == MMAE_BF16) {
+    bool fast = false;
+    if (inner == 512 && ns >= 2 && ns <= 5)
+        fast = dtype == MMAE_BF16 ? (head_dim == 64 ? modattn_bwd_fast<bf16, 64>(p, grid, st) : modattn_bwd_fast<bf16, 32>(p, grid, st))
+                                  : (head_dim == 64 ? modattn_bwd_fast<float, 64>(p, grid, st) : modattn_bwd_fast<float, 32>(p, grid, st));
+    if (fast) {
+    } else if (dtype == MMAE_BF16) {
         if (head_dim == 64) { if (two) GO(bf16, 64, 2); else GO(bf16, 64, 1); } else { if (two) GO(bf16, 32, 2); else GO(bf16, 32, 1); }
     } else {
         if (head_dim == 64) { if (two) GO(float, 64, 2); else GO(float, 64, 1); } else { if (two) GO(float, 32, 2); else GO(float, 32, 1); }

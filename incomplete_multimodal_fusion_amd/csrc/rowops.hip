@@ -464,6 +464,424 @@ __global__ __launch_bounds__(256) void add_ln_bwd_dual_kernel(AddLnBwdDual p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ fast paths (D == 256 * NC, no beta)
+// The generic kernels above guard every 256-column chunk with `col < D` and every optional operand with a pointer test.  In
+// the generated code each guard is a branch of its own with an s_waitcnt vmcnt(0) behind it: the three chunks of a 768-wide
+// row were fetched one after the other, 6-12 dependent trips to memory per row, and the row reductions went through the LDS
+// crossbar (ds_bpermute).  The kernels below are the same arithmetic for full rows with the optional operands as template
+// flags: one basic block per row, every load of the row in flight at once, reductions on DPP + permlane swaps (VALU only).
+// raw (unconverted) 4-element row pieces: the loads of a row are issued as one group and converted where they are used
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16> { typedef u32x2 type; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::type ld4raw(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4raw<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+template <> __device__ __forceinline__ u32x2 ld4raw<bf16>(const bf16* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)); }
+__device__ __forceinline__ f32x4 cvt4(const f32x4& r) { return r; }
+__device__ __forceinline__ f32x4 cvt4(const u32x2& r) {
+    return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+}
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_v(float v) {
+    v += dpp_get<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v += dpp_get<0x124>(v);                // row_ror:4
+    v += dpp_get<0x128>(v);                // row_ror:8  -> every lane: sum of its 16-lane row
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+template <typename TD, typename TY, int NC, bool DOUBLE, bool HAS_DELTA>
+__global__ __launch_bounds__(256) void add_ln_fwd_fast_kernel(AddLnFwd p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    constexpr int D = 256 * NC;
+    constexpr float invD = 1.f / (float)D;
+    const long at = row * D + 4 * lane;
+    f32x4 v[NC], dl[NC], G1[NC], G2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = ld4s<float>(p.x + at + 256 * c);
+    if (HAS_DELTA)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dl[c] = ld4s<TD>(reinterpret_cast<const TD*>(p.delta) + at + 256 * c);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        G1[c] = ld4f<float>(p.g1 + 4 * lane + 256 * c);
+        if (DOUBLE) G2[c] = ld4f<float>(p.g2 + 4 * lane + 256 * c);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (HAS_DELTA) { v[c] += dl[c]; st4s<float>(p.x_new + at + 256 * c, v[c]); }
+        s += sum4(v[c]);
+    }
+    const float m1 = wave_sum_v(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { v[c] = v[c] - m1; q += sum4(v[c] * v[c]); }
+    const float r1 = rsqrtf(wave_sum_v(q) * invD + p.eps1);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { v[c] = v[c] * r1 * G1[c]; s2 += sum4(v[c]); }
+    float m2 = 0.f, r2 = 1.f;
+    if (DOUBLE) {
+        m2 = wave_sum_v(s2) * invD;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { v[c] = v[c] - m2; q2 += sum4(v[c] * v[c]); }
+        r2 = rsqrtf(wave_sum_v(q2) * invD + p.eps2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = v[c] * r2 * G2[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) st4s<TY>(reinterpret_cast<TY*>(p.y) + at + 256 * c, v[c]);
+    if (lane == 0) *reinterpret_cast<f32x4*>(p.stats + row * 4) = f32x4{m1, r1, m2, r2};
+}
+
+// persistent: 4 rows per block in flight, gamma vectors in LDS, column sums [dg1, -, dg2, -] in registers
+template <typename TD, typename TY, int NC, bool DOUBLE, bool UP, bool GX, bool GD>
+__global__ __launch_bounds__(256) void add_ln_bwd_fast_kernel(AddLnBwd p) {
+    constexpr int D = 256 * NC;
+    constexpr float invD = 1.f / (float)D;
+    __shared__ __attribute__((aligned(16))) float red[6 * D];     // [4 waves][D] reduction scratch, then g1, g2
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sg1 = red + 4 * D; float* sg2 = sg1 + D;
+    for (int c = threadIdx.x; c < D; c += 256) { sg1[c] = p.g1[c]; sg2[c] = DOUBLE ? p.g2[c] : 0.f; }
+    __syncthreads();
+    const f32x4 z4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dg1[NC], dg2[DOUBLE ? NC : 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { dg1[c] = z4; if (DOUBLE) dg2[c] = z4; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const long at = row * D + 4 * lane;
+        int z = 0;                                                    // opaque zero: the gamma reads below stay LDS reads of this
+        asm volatile("" : "+s"(z));                                   // iteration (hoisted out of the loop they cost 24 VGPRs)
+        const float* g1l = sg1 + z + 4 * lane; const float* g2l = sg2 + z + 4 * lane;
+        f32x4 xh[NC], gv[NC], up[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xh[c] = ld4s<float>(p.x_new + at + 256 * c);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gv[c] = ld4s<TY>(reinterpret_cast<const TY*>(p.gy) + at + 256 * c);
+        if (UP)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) up[c] = ld4s<float>(p.gx_up + at + 256 * c);
+        const f32x4 st = *reinterpret_cast<const f32x4*>(p.stats + row * 4);
+        const float m1 = st[0], r1 = st[1], m2 = st[2], r2 = st[3];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xh[c] = (xh[c] - m1) * r1;
+        if (DOUBLE) {
+            f32x4 uh[NC];
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uh[c] = (xh[c] * *reinterpret_cast<const f32x4*>(g1l + 256 * c) - m2) * r2;
+                dg2[c] += gv[c] * uh[c];
+                gv[c] = gv[c] * *reinterpret_cast<const f32x4*>(g2l + 256 * c);
+                a += sum4(gv[c]); bsum += sum4(gv[c] * uh[c]);
+            }
+            const float c1 = wave_sum_v(a) * invD, c2 = wave_sum_v(bsum) * invD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) gv[c] = (gv[c] - c1 - uh[c] * c2) * r2;      // grad wrt u = xhat * g1
+        }
+        float a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            dg1[c] += gv[c] * xh[c];
+            gv[c] = gv[c] * *reinterpret_cast<const f32x4*>(g1l + 256 * c);   // grad wrt xhat
+            a3 += sum4(gv[c]); a4 += sum4(gv[c] * xh[c]);
+        }
+        const float c3 = wave_sum_v(a3) * invD, c4 = wave_sum_v(a4) * invD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 gx = (gv[c] - c3 - xh[c] * c4) * r1;
+            if (UP) gx += up[c];
+            if (GX) st4s<float>(p.gx + at + 256 * c, gx);
+            if (GD) st4s<TD>(reinterpret_cast<TD*>(p.gdelta) + at + 256 * c, gx);
+        }
+    }
+#pragma unroll
+    for (int qn = 0; qn < 4; qn += 2) {                               // [dg1, (dbeta1), dg2, (dbeta2)]: no beta on this path
+        if (!DOUBLE && qn >= 2) break;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<f32x4*>(red + wave * D + 4 * lane + 256 * c) = qn == 0 ? dg1[c] : dg2[DOUBLE ? c : 0];
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += 256)
+            p.ws[((long)blockIdx.x * 4 + qn) * D + col] = red[col] + red[D + col] + red[2 * D + col] + red[3 * D + col];
+    }
+}
+
+template <typename TD, typename TY, int NC, bool HAS_DELTA>
+__global__ __launch_bounds__(256) void add_ln_fwd_dual_fast_kernel(AddLnFwdDual p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    constexpr int D = 256 * NC;
+    constexpr float invD = 1.f / (float)D;
+    const long at = row * D + 4 * lane;
+    f32x4 v[NC], dl[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = ld4s<float>(p.x + at + 256 * c);
+    if (HAS_DELTA)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dl[c] = ld4s<TD>(reinterpret_cast<const TD*>(p.delta) + at + 256 * c);
+    f32x4 G1[2][NC], G2[2][NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        G1[0][c] = ld4f<float>(p.g1a + 4 * lane + 256 * c); G2[0][c] = ld4f<float>(p.g2a + 4 * lane + 256 * c);
+        G1[1][c] = ld4f<float>(p.g1b + 4 * lane + 256 * c); G2[1][c] = ld4f<float>(p.g2b + 4 * lane + 256 * c);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (HAS_DELTA) { v[c] += dl[c]; st4s<float>(p.x_new + at + 256 * c, v[c]); }
+        s += sum4(v[c]);
+    }
+    const float m1 = wave_sum_v(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { v[c] = v[c] - m1; q += sum4(v[c] * v[c]); }
+    const float r1 = rsqrtf(wave_sum_v(q) * invD + p.eps1);
+    // both second LayerNorms side by side: their reductions are independent, so the four wave sums overlap pairwise
+    f32x4 u[2][NC];
+    float s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[c] = v[c] * r1;                                              // xhat, shared by both paths
+#pragma unroll
+        for (int path = 0; path < 2; ++path) { u[path][c] = v[c] * G1[path][c]; s2[path] += sum4(u[path][c]); }
+    }
+    const float m2a = wave_sum_v(s2[0]) * invD, m2b = wave_sum_v(s2[1]) * invD;
+    float q2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        u[0][c] = u[0][c] - m2a; q2[0] += sum4(u[0][c] * u[0][c]);
+        u[1][c] = u[1][c] - m2b; q2[1] += sum4(u[1][c] * u[1][c]);
+    }
+    const float r2a = rsqrtf(wave_sum_v(q2[0]) * invD + p.eps2), r2b = rsqrtf(wave_sum_v(q2[1]) * invD + p.eps2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        st4s<TY>(reinterpret_cast<TY*>(p.ya) + at + 256 * c, u[0][c] * r2a * G2[0][c]);
+        st4s<TY>(reinterpret_cast<TY*>(p.yb) + at + 256 * c, u[1][c] * r2b * G2[1][c]);
+    }
+    if (lane == 0) {
+        *reinterpret_cast<f32x4*>(p.stats_a + row * 4) = f32x4{m1, r1, m2a, r2a};
+        *reinterpret_cast<f32x4*>(p.stats_b + row * 4) = f32x4{m1, r1, m2b, r2b};
+    }
+}
+
+template <typename TD, typename TY, int NC, bool UP, bool GX, bool GD>
+__global__ __launch_bounds__(256, NC <= 3 ? 3 : 2) void add_ln_bwd_dual_fast_kernel(AddLnBwdDual p) {
+    constexpr int D = 256 * NC;
+    constexpr float invD = 1.f / (float)D;
+    __shared__ __attribute__((aligned(16))) float red[8 * D];     // [4 waves][D] reduction scratch, then g1a, g2a, g1b, g2b
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sg = red + 4 * D;                                      // sg + (2 * path + k) * D
+    for (int c = threadIdx.x; c < D; c += 256) {
+        sg[c] = p.g1a[c]; sg[D + c] = p.g2a[c]; sg[2 * D + c] = p.g1b[c]; sg[3 * D + c] = p.g2b[c];
+    }
+    __syncthreads();
+    const f32x4 z4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dg[4][NC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dg[k][c] = z4;
+    const int lo = 4 * lane;
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        // wave-uniform row bases + a 32-bit lane offset: the loads take the scalar-base form (no 64-bit address pairs in VGPRs)
+        const float* xr = p.x_new + row * D;
+        const TY* gar = reinterpret_cast<const TY*>(p.gya) + row * D;
+        const TY* gbr = reinterpret_cast<const TY*>(p.gyb) + row * D;
+        f32x4 xh[NC], up[NC], tot[NC];
+        typename Raw4<TY>::type gar_[NC], gbr_[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xh[c] = ld4s<float>(xr + lo + 256 * c);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            gar_[c] = ld4raw<TY>(gar + lo + 256 * c);
+            gbr_[c] = ld4raw<TY>(gbr + lo + 256 * c);
+        }
+        if (UP) {
+            const float* upr = p.gx_up + row * D;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) up[c] = ld4s<float>(upr + lo + 256 * c);
+        }
+        const f32x4 sta = *reinterpret_cast<const f32x4*>(p.stats_a + row * 4);
+        const f32x4 stb = *reinterpret_cast<const f32x4*>(p.stats_b + row * 4);
+        __builtin_amdgcn_sched_barrier(0);                            // every load of the row is in flight before anything is used
+        const float m1 = sta[0], r1 = sta[1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xh[c] = (xh[c] - m1) * r1;
+        // one path after the other (their live sets do not overlap: 168 VGPRs hold the row, the four column sums and one path)
+#pragma unroll
+        for (int path = 0; path < 2; ++path) {
+            const float m2 = path ? stb[2] : sta[2], r2 = path ? stb[3] : sta[3];
+            int z = 0;                                                // opaque zeros: the gamma reads stay LDS reads of this
+            asm volatile("" : "+s"(z));                               // iteration, and uh is RE-computed after the reductions
+            const float* G1 = sg + 2 * path * D + z + lo; const float* G2 = G1 + D;
+            float a = 0.f, bsum = 0.f;
+            f32x4 gvv[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4& gv = gvv[c];
+                gv = cvt4(path ? gbr_[c] : gar_[c]);
+                const f32x4 uh = (xh[c] * *reinterpret_cast<const f32x4*>(G1 + 256 * c) - m2) * r2;
+                dg[2 * path + 1][c] += gv * uh;
+                gv = gv * *reinterpret_cast<const f32x4*>(G2 + 256 * c);
+                a += sum4(gv); bsum += sum4(gv * uh);
+            }
+            const float c1 = wave_sum_v(a) * invD, c2 = wave_sum_v(bsum) * invD;
+            int z2 = 0;
+            asm volatile("" : "+s"(z2));
+            const float* G1b = sg + 2 * path * D + z2 + lo;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4& gv = gvv[c];
+                const f32x4 g1v = *reinterpret_cast<const f32x4*>(G1b + 256 * c);
+                const f32x4 uh = (xh[c] * g1v - m2) * r2;
+                const f32x4 gu = (gv - c1 - uh * c2) * r2;                // grad wrt u = xhat * g1
+                dg[2 * path][c] += gu * xh[c];
+                tot[c] = path ? tot[c] + gu * g1v : gu * g1v;            // grad wrt xhat, both paths summed
+            }
+        }
+        float a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { a3 += sum4(tot[c]); a4 += sum4(tot[c] * xh[c]); }
+        const float c3 = wave_sum_v(a3) * invD, c4 = wave_sum_v(a4) * invD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 gx = (tot[c] - c3 - xh[c] * c4) * r1;
+            if (UP) gx += up[c];
+            if (GX) st4s<float>(p.gx + row * D + lo + 256 * c, gx);
+            if (GD) st4s<TD>(reinterpret_cast<TD*>(p.gdelta) + row * D + lo + 256 * c, gx);
+        }
+    }
+#pragma unroll
+    for (int qn = 0; qn < 4; ++qn) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(red + wave * D + lo + 256 * c) = dg[qn][c];
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += 256)
+            p.ws[((long)blockIdx.x * 4 + qn) * D + col] = red[col] + red[D + col] + red[2 * D + col] + red[3 * D + col];
+    }
+}
+
+// blocks of the persistent backward kernels: what is resident at once (256 CUs x blocks per CU at the kernel's footprint)
+template <typename K> static int resident_blocks(K kernel, int fallback) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return fallback;
+    return per_cu * 256;
+}
+
+
+// ---- dispatch of the fast paths: widths 768 (ViT-B) and 1024 (ViT-L); every other width runs the generic kernels
+static bool ln_fast_width(int D) { return D == 768 || D == 1024; }
+
+template <typename TD, typename TY, int NC>
+static int add_ln_fwd_fast_t(const AddLnFwd& p, hipStream_t st) {
+    dim3 grid(cdiv(p.rows, 4)), blk(256);
+    const bool dbl = p.g2 != nullptr;
+    if (p.delta) {
+        if (dbl) MMAE_LAUNCH((add_ln_fwd_fast_kernel<TD, TY, NC, true, true>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((add_ln_fwd_fast_kernel<TD, TY, NC, false, true>), grid, blk, 0, st, p);
+    } else {
+        if (dbl) MMAE_LAUNCH((add_ln_fwd_fast_kernel<bf16, TY, NC, true, false>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((add_ln_fwd_fast_kernel<bf16, TY, NC, false, false>), grid, blk, 0, st, p);
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+#define LN_FAST_TYPES(FN, ...)                                                                                   \
+    (dtype_delta == MMAE_BF16                                                                                    \
+         ? (dtype_y == MMAE_BF16 ? (nc3 ? FN<bf16, bf16, 3>(__VA_ARGS__) : FN<bf16, bf16, 4>(__VA_ARGS__))       \
+                                 : (nc3 ? FN<bf16, float, 3>(__VA_ARGS__) : FN<bf16, float, 4>(__VA_ARGS__)))    \
+         : (dtype_y == MMAE_BF16 ? (nc3 ? FN<float, bf16, 3>(__VA_ARGS__) : FN<float, bf16, 4>(__VA_ARGS__))     \
+                                 : (nc3 ? FN<float, float, 3>(__VA_ARGS__) : FN<float, float, 4>(__VA_ARGS__))))
+static int add_ln_fwd_fast(int dtype_delta, int dtype_y, const AddLnFwd& p, hipStream_t st) {
+    const bool nc3 = p.D == 768;
+    return LN_FAST_TYPES(add_ln_fwd_fast_t, p, st);
+}
+
+// (UP, GX, GD) as template flags; the delta type only matters when gdelta is written
+template <typename TD, typename TY, int NC, bool DOUBLE, bool UP, bool GX>
+static int add_ln_bwd_fast_f(const AddLnBwd& p, long want, int* used, hipStream_t st) {
+#define GO(KERNEL)                                                                              \
+    {                                                                                           \
+        static const int resident = resident_blocks(KERNEL, 768);                               \
+        long nb = want < resident ? want : resident; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; \
+        *used = (int)nb;                                                                        \
+        MMAE_LAUNCH(KERNEL, dim3((unsigned)nb), dim3(256), 0, st, p);                           \
+    }
+    if (p.gdelta) GO((add_ln_bwd_fast_kernel<TD, TY, NC, DOUBLE, UP, GX, true>))
+    else GO((add_ln_bwd_fast_kernel<bf16, TY, NC, DOUBLE, UP, GX, false>))
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+template <typename TD, typename TY, int NC>
+static int add_ln_bwd_fast_t(const AddLnBwd& p, long want, int* used, hipStream_t st) {
+    const bool dbl = p.g2 != nullptr, up = p.gx_up != nullptr, gx = p.gx != nullptr;
+#define F(DB, U, G) add_ln_bwd_fast_f<TD, TY, NC, DB, U, G>(p, want, used, st)
+    if (dbl) return up ? (gx ? F(true, true, true) : F(true, true, false)) : (gx ? F(true, false, true) : F(true, false, false));
+    return up ? (gx ? F(false, true, true) : F(false, true, false)) : (gx ? F(false, false, true) : F(false, false, false));
+#undef F
+}
+static int add_ln_bwd_fast(int dtype_delta, int dtype_y, const AddLnBwd& p, long want, int* used, hipStream_t st) {
+    const bool nc3 = p.D == 768;
+    return LN_FAST_TYPES(add_ln_bwd_fast_t, p, want, used, st);
+}
+
+template <typename TD, typename TY, int NC>
+static int add_ln_fwd_dual_fast_t(const AddLnFwdDual& p, hipStream_t st) {
+    dim3 grid(cdiv(p.rows, 4)), blk(256);
+    if (p.delta) MMAE_LAUNCH((add_ln_fwd_dual_fast_kernel<TD, TY, NC, true>), grid, blk, 0, st, p);
+    else MMAE_LAUNCH((add_ln_fwd_dual_fast_kernel<bf16, TY, NC, false>), grid, blk, 0, st, p);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+static int add_ln_fwd_dual_fast(int dtype_delta, int dtype_y, const AddLnFwdDual& p, hipStream_t st) {
+    const bool nc3 = p.D == 768;
+    return LN_FAST_TYPES(add_ln_fwd_dual_fast_t, p, st);
+}
+
+template <typename TD, typename TY, int NC, bool UP, bool GX>
+static int add_ln_bwd_dual_fast_f(const AddLnBwdDual& p, long want, int* used, hipStream_t st) {
+#define GO(KERNEL)                                                                              \
+    {                                                                                           \
+        static const int resident = resident_blocks(KERNEL, 512);                               \
+        long nb = want < resident ? want : resident; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; \
+        *used = (int)nb;                                                                        \
+        MMAE_LAUNCH(KERNEL, dim3((unsigned)nb), dim3(256), 0, st, p);                           \
+    }
+    if (p.gdelta) GO((add_ln_bwd_dual_fast_kernel<TD, TY, NC, UP, GX, true>))
+    else GO((add_ln_bwd_dual_fast_kernel<bf16, TY, NC, UP, GX, false>))
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+template <typename TD, typename TY, int NC>
+static int add_ln_bwd_dual_fast_t(const AddLnBwdDual& p, long want, int* used, hipStream_t st) {
+    const bool up = p.gx_up != nullptr, gx = p.gx != nullptr;
+    if (up) return gx ? add_ln_bwd_dual_fast_f<TD, TY, NC, true, true>(p, want, used, st) : add_ln_bwd_dual_fast_f<TD, TY, NC, true, false>(p, want, used, st);
+    return gx ? add_ln_bwd_dual_fast_f<TD, TY, NC, false, true>(p, want, used, st) : add_ln_bwd_dual_fast_f<TD, TY, NC, false, false>(p, want, used, st);
+}
+static int add_ln_bwd_dual_fast(int dtype_delta, int dtype_y, const AddLnBwdDual& p, long want, int* used, hipStream_t st) {
+    const bool nc3 = p.D == 768;
+    return LN_FAST_TYPES(add_ln_bwd_dual_fast_t, p, want, used, st);
+}
+
 #define DISPATCH_TD_TY(FN, ...)                                                                         \
     (dtype_delta == MMAE_BF16                                                                           \
          ? (dtype_y == MMAE_BF16 ? (dbl ? FN<bf16, bf16, true>(__VA_ARGS__) : FN<bf16, bf16, false>(__VA_ARGS__))    \
@@ -482,6 +900,7 @@ extern "C" int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, c
     AddLnFwd p{x, delta, delta ? x_new : nullptr, y, gamma1, beta1, gamma2, beta2, eps1, eps2, stats, rows, D};
     if (delta && !x_new) return MMAE_ERR_ARG;
     const bool dbl = gamma2 != nullptr;
+    if (ln_fast_width(D) && !beta1 && !beta2) return add_ln_fwd_fast(dtype_delta, dtype_y, p, reinterpret_cast<hipStream_t>(stream));
     return DISPATCH_TD_TY(add_ln_fwd_nc, p, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -502,7 +921,14 @@ extern "C" int mmae_add_ln_bwd(int dtype_delta, int dtype_y, long rows, int D, c
     const bool dbl = gamma2 != nullptr;
     // dbeta outputs are only produced (non-zero) when the kernel keeps beta accumulators
     const bool hasb = beta1 != nullptr || dbeta1 != nullptr || dbeta2 != nullptr;
-    int rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, hasb, st);
+    int rc;
+    if (ln_fast_width(D) && !hasb) {
+        int fast_blocks = 0;
+        rc = add_ln_bwd_fast(dtype_delta, dtype_y, p, nblk, &fast_blocks, st);
+        nblk = fast_blocks;
+    } else {
+        rc = DISPATCH_TD_TY(add_ln_bwd_nc, p, (int)nblk, hasb, st);
+    }
     if (rc) return rc;
     MMAE_LAUNCH(colsum_finalize_kernel, dim3(cdiv(D, 64), dbl ? 4 : 2), dim3(1024), 0, st, ws, (int)nblk, D,
                        dgamma1, dbeta1, dgamma2, dbeta2, accumulate);
@@ -522,6 +948,7 @@ extern "C" int mmae_add_ln_fwd_dual(int dtype_delta, int dtype_y, long rows, int
     AddLnFwdDual p{x, delta, delta ? x_new : nullptr, y_a, y_b, gamma1_a, gamma2_a, gamma1_b, gamma2_b, eps1, eps2, stats_a, stats_b, rows, D};
     dim3 grid(cdiv(rows, 4)), blk(256);
     const int nc = cdiv(D, 256);
+    if (ln_fast_width(D)) return add_ln_fwd_dual_fast(dtype_delta, dtype_y, p, st);
 #define GO(TD, TY)                                                                                    \
     switch (nc) {                                                                                     \
         case 1: MMAE_LAUNCH((add_ln_fwd_dual_kernel<TD, TY, 1>), grid, blk, 0, st, p); break;         \
@@ -551,6 +978,15 @@ extern "C" int mmae_add_ln_bwd_dual(int dtype_delta, int dtype_y, long rows, int
     dim3 grid((unsigned)nblk), blk(256);
     const size_t lds = (size_t)8 * D * sizeof(float);
     const int nc = cdiv(D, 256);
+    if (ln_fast_width(D)) {
+        int fast_blocks = 0;
+        const int rc = add_ln_bwd_dual_fast(dtype_delta, dtype_y, p, (rows + 3) / 4, &fast_blocks, st);
+        if (rc) return rc;
+        MMAE_LAUNCH(colsum_finalize_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, st, ws, fast_blocks, D,
+                    dgamma1_a, dgamma2_a, dgamma1_b, dgamma2_b, accumulate);
+        MMAE_CHECK_LAUNCH();
+        return MMAE_OK;
+    }
 #define GO(TD, TY)                                                                                      \
     switch (nc) {                                                                                       \
         case 1: MMAE_LAUNCH((add_ln_bwd_dual_kernel<TD, TY, 1>), grid, blk, lds, st, p); break;         \

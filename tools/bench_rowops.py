@@ -72,6 +72,22 @@ def add_ln(args, call, ptr, stream, lib):
     bf, bb = rows * D * (4 + 2 + 4 + 2), rows * D * (4 + 2 + 4 + 4 + 2)
     print("            add_ln_fwd %.1f us (%.2f TB/s)   add_ln_bwd (gx_up, gx, gdelta) %.1f us (%.2f TB/s)" %
           (t_f, bf / t_f / 1e6, t_b, bb / t_b / 1e6))
+    # dual double-LayerNorm of the modality rows (B * N = 98304 rows at the bench batch)
+    rows = rows * 3 // 5
+    x = x[:rows]; delta = delta[:rows]; xn = xn[:rows]; y = y[:rows]; gy = gy[:rows]; gup = gup[:rows]; gx = gx[:rows]; gd = gd[:rows]
+    yb = torch.empty_like(y); gyb = torch.randn(rows, D, device=dev).to(torch.bfloat16)
+    g1b = torch.rand(D, device=dev) + 0.5; g2b = torch.rand(D, device=dev) + 0.5
+    stats_b = torch.empty(rows, 4, device=dev)
+    dg1b = torch.zeros(D, device=dev); dg2b = torch.zeros(D, device=dev)
+    fwd = lambda: call("mmae_add_ln_fwd_dual", 1, 1, rows, D, ptr(x), ptr(delta), ptr(xn), ptr(y), ptr(yb), ptr(g1), ptr(g2), ptr(g1b),
+                       ptr(g2b), 1e-5, 1e-5, ptr(stats), ptr(stats_b), stream())
+    t_f = timeit(fwd)
+    bwd = lambda: call("mmae_add_ln_bwd_dual", 1, 1, rows, D, ptr(xn), ptr(gy), ptr(gyb), ptr(gup), ptr(g1), ptr(g2), ptr(g1b), ptr(g2b),
+                       ptr(stats), ptr(stats_b), ptr(gx), ptr(gd), ptr(dg1), ptr(dg2), ptr(dg1b), ptr(dg2b), ptr(ws), 0, stream())
+    t_b = timeit(bwd)
+    bf, bb = rows * D * (4 + 2 + 4 + 2 + 2), rows * D * (4 + 2 + 2 + 4 + 4 + 2)
+    print("            add_ln_fwd_dual %.1f us (%.2f TB/s)   add_ln_bwd_dual %.1f us (%.2f TB/s)   [%d rows]" %
+          (t_f, bf / t_f / 1e6, t_b, bb / t_b / 1e6, rows))
 
 
 def modattn(args):
