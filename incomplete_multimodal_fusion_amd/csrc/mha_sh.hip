@@ -316,7 +316,10 @@ __device__ __forceinline__ void sh_zero_rows(const MhaDesc& p, long row0, int n,
 // are covered by the others without hand-interleaving (the first version of this kernel -- 8 waves with both slots in every
 // wave, 212 VGPRs, two waves per SIMD running the same code in lock-step -- measured 230-240 us at the bench shape with
 // 41 % of wave cycles parked and 22 % issue-stalled: no faster than the tile-per-block kernel).
-template <int MODE>
+// TPB = key tiles per workgroup barrier.  2: the loop body runs twice behind one s_barrier -- half the barriers, half the points
+// at which 16 waves wait for the slowest one (a slot switch, a finish, a loader still issuing); the ring then holds the pair
+// being consumed and the pair in flight (4 stages, tiles issued one pair-iteration ahead of their use).
+template <int MODE, int TPB>
 __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     __shared__ __attribute__((aligned(1024))) bf16 ringK[SH_NS][4096];
     __shared__ __attribute__((aligned(1024))) bf16 ringV[SH_NS][4096];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     find_next(0, 0, 0);
     if (nh >= 0) issue_q(nsg, chunk_of(np_), h0 + nh);
     mark = vm;
-    for (int i = 0; i < SH_D && i < G; ++i) issue_ring();
+    for (int i = 0; i < (TPB == 2 ? SH_NS : SH_D) && i < G; ++i) issue_ring();
 
     bool act = false, fresh = false;
     int t = 0, pi = 0, hi = 0;
@@ -473,11 +476,15 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     if (ST) { tl = sh_now(); t_loop = tl; }
     int stage = 0;                                                  // ring stage of tile g
     for (int g = 0; g < G; ++g) {
-        if (wave == 12 + (g & 3)) sh_wait_vm(vm - myseq);         // the pieces of tile g were mine to fetch
-        SH_T(0);
-        __builtin_amdgcn_s_barrier();
-        SH_T(1);
-        if (lj < G) issue_ring();
+        if (TPB == 1 || (g & 1) == 0) {
+            if (wave == 12 + (g & 3)) sh_wait_vm(vm - myseq);     // the pieces of tile g were mine to fetch
+            if (TPB == 2 && g + 1 < G && wave == 12 + ((g + 1) & 3)) sh_wait_vm(vm - myseq);
+            SH_T(0);
+            __builtin_amdgcn_s_barrier();
+            SH_T(1);
+            if (TPB == 1) { if (lj < G) issue_ring(); }
+            else if (g >= 2) { if (lj < G) issue_ring(); if (lj < G) issue_ring(); }   // into the stages of the pair just finished
+        }
         const int tinf = t_info(t), kn = tinf & 255, sg = (tinf >> 8) & 255, fl = tinf >> 16;
         const int h = h0 + hi;
         SH_T(2);
@@ -1105,14 +1112,17 @@ int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
     if (d.max_k_rows / 64 + d.nseg > SH_MAXT || d.k_stride != d.v_stride || d.nseg > MAXSEG) return MMAE_ERR_ARG;
     const int hpb = sh_heads_per_block(d.B, d.H);
     const dim3 grid(d.B * (d.H / hpb)), blk(1024);
-    if (mode == 1) MMAE_LAUNCH(mha_sh_fwd_kernel<1>, grid, blk, 0, st, d, hpb);
-    else if (mode == 2) MMAE_LAUNCH(mha_sh_fwd_kernel<2>, grid, blk, 0, st, d, hpb);
+    if (mode == 1) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 1>), grid, blk, 0, st, d, hpb);
 #if MMAE_DIAG
-    else if (mode == 3) MMAE_LAUNCH(mha_sh_fwd_kernel<3>, grid, blk, 0, st, d, hpb);
+    else if (mode == 3) MMAE_LAUNCH((mha_sh_fwd_kernel<3, 1>), grid, blk, 0, st, d, hpb);
 #else
     else if (mode == 3) return MMAE_ERR_ARG;
 #endif
-    else MMAE_LAUNCH(mha_sh_fwd_kernel<0>, grid, blk, 0, st, d, hpb);
+    else if (mode == 10) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 2>), grid, blk, 0, st, d, hpb);     // two tiles per barrier
+    else if (mode == 11) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 2>), grid, blk, 0, st, d, hpb);
+    else if (mode == 12) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 2>), grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH((mha_sh_fwd_kernel<0, 1>), grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -364,9 +364,15 @@ class _MHA(torch.autograd.Function):
         return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None, None
 
 
-def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv", variant: int = 0) -> torch.Tensor:
+MHA_SELF_VARIANT = int(os.environ.get("MMAE_MHA_VARIANT", "0"))   # tuning knob (A/B runs of bench.py): variant of mha_self calls
+
+
+def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv", variant: Optional[int] = None) -> torch.Tensor:
     """Self attention on a fused projection output qkv (rows, 3*H*dh) laid out [q | k | v] column blocks.
     variant != 0: test / tuning kernels through csrc/mmae_internal.h (per call, no global state)."""
+    variant = MHA_SELF_VARIANT if variant is None else variant
+    if variant and dh != 64:
+        variant = 0
     I = H * dh
     return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0, variant)
 
@@ -494,7 +500,10 @@ class _PartsAddLN(torch.autograd.Function):
                torch.empty(D, dtype=torch.float32, device=dev) if has_b1 else None,
                torch.empty(D, dtype=torch.float32, device=dev) if dbl else None,
                torch.empty(D, dtype=torch.float32, device=dev) if (dbl and has_b2) else None]
-        accb = [torch.zeros(D, dtype=torch.float32, device=dev), torch.zeros(D, dtype=torch.float32, device=dev)] \
+        # the second pair's sums are ASSIGNED when the dual part is the first non-empty part (always, in the model: part 0);
+        # only then may the buffers start uninitialised
+        dual_first = dual is not None and all(rows[j] == 0 for j in range(dual[0])) and rows[dual[0]] > 0
+        accb = [(torch.empty if dual_first else torch.zeros)(D, dtype=torch.float32, device=dev) for _ in range(2)] \
             if dual is not None else [None, None]
         ws = torch.empty(_lib.lib().mmae_add_ln_bwd_ws_floats(max(rows), D), dtype=torch.float32, device=dev)
         gxs = []
