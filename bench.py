@@ -238,13 +238,16 @@ def mfma_busy():
 def event_bracket_overhead_ms(device, n=96):
     """What a HIP-event bracket measures around NOTHING on a busy stream: the two event packets are each processed after
     the preceding work drains, so every bracket of ops.KernelTimer carries this constant on top of the kernel's own
-    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms elementwise kernel
-    keeps the queue busy (not a GEMM: TunableOp would tune the new shape), then an empty bracket -- and subtracted from the
-    roofline legs' averages; both figures are printed."""
-    a = torch.zeros(64 << 20, device=device, dtype=torch.float32)
+    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms elementwise kernel of
+    the library (mmae_gelu_fwd over 128 Mi bf16 elements; not a GEMM: TunableOp would tune the new shape) keeps the queue
+    busy, then an empty bracket -- and subtracted from the roofline legs' averages; both figures are printed.  (In a rocprofv3
+    summary of bench.py these n launches show up as `gelu_fwd_kernel` calls of ~85 us outside every timed step.)"""
+    from incomplete_multimodal_fusion_amd._lib import call, ptr, stream
+    a = torch.zeros(128 << 20, device=device, dtype=torch.bfloat16)
+    b = torch.empty_like(a)
     pairs = []
     for _ in range(n):
-        a.add_(1.0)
+        call("mmae_gelu_fwd", 1, a.numel(), ptr(a), ptr(b), stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()
         pairs.append((e0, e1))

@@ -34,6 +34,8 @@ from .zorro_utils import (Attention, Block, Block_Fusion, LayerNorm, Mlp, TokenT
 __all__ = ['pretrain_multimae_tiny', 'pretrain_multimae_base', 'pretrain_multimae_large', 'MultiMAE']
 
 
+FUSED_DECODER_CTX = os.environ.get('MMAE_FUSED_CTX', '1') != '0'   # A/B knob: one GEMM for every decoder's proj_context
+
 class PredTokens:
     """Decoder output kept token-major, (B*P, C*p*p) in (c ph pw) order, so that the masked loss can be fused with the
     unpatchify.  Quacks like the prediction tensor for the reference driver (`preds[task].float()`,
@@ -383,7 +385,18 @@ class MultiMAE(nn.Module):
         # ---- attention pooling into the return tokens (:475-497) ---------------------------------------------------------
         ap = self.attn_pool
         R = self.max_return_tokens
-        kvp = linear(tokens_T, ap.to_kv.weight, once=True)                                             # (BN+BP, 2I), context un-normalised
+        # pool K/V over every row + (training forward) the context projection of EVERY decoder over the fusion rows: one node,
+        # one GEMM for the three proj_context layers (ops._KvCtx).  fp32 output adapters keep their own fp32 projection.
+        fused_ctx = FUSED_DECODER_CTX and self.output_adapters is not None and len(self.output_adapters) > 0 and not fp32_output_adapters and \
+            all(hasattr(a, 'decode_rows') and a.dim_tokens_enc is not None for a in self.output_adapters.values())
+        if fused_ctx:
+            ads = list(self.output_adapters.values())
+            kvp, ctx_all = ops.kv_ctx_projections(tokens_T, BN, BP, ap.to_kv.weight, [a.proj_context.weight for a in ads],
+                                                  [a.proj_context.bias for a in ads])
+            ctx_rows = dict(zip(self.output_adapters.keys(),
+                                ops.split_cols_f32(ctx_all, [a.dim_tokens for a in ads], [a.own_task_embedding() for a in ads])))
+        else:
+            kvp = linear(tokens_T, ap.to_kv.weight, once=True)                                         # (BN+BP, 2I), context un-normalised
         rq = linear(ops.layernorm(self.return_tokens[0].contiguous(), ap.norm.gamma, out_dtype=T), ap.to_q.weight)
         a = ops.mha_cross(rq.repeat(B, 1), kvp, Hh, dh, desc.pool_q, desc.enc_seg, ap.scale, empty_mode=0)
         pooled = linear(a, ap.to_out.weight).float()                                        # (B*R, D)
@@ -418,9 +431,10 @@ class MultiMAE(nn.Module):
                 # autocast region in fp32) -- not the bf16 copy widened again
                 rows = tokens[BN:] if d in fp32_output_adapters else enc_rows
                 with torch.autocast("cuda", enabled=False) if d in fp32_output_adapters else _nullctx():
-                    tk = adapter.forward_tokens(rows, B, P, dec_seg, once=True)
+                    tk = adapter.decode_rows(ctx_rows[d], B, P, dec_seg, True, T) if fused_ctx else \
+                        adapter.forward_tokens(rows, B, P, dec_seg, once=True)
                 if st_ is not main:
-                    rows.record_stream(st_)
+                    (ctx_rows[d] if fused_ctx else rows).record_stream(st_)
                     tk.record_stream(main)
             C = adapter.num_channels
             preds[d] = PredTokens(tk, B, C, H, W, adapter.P_H) if self.fuse_unpatchify_loss else \

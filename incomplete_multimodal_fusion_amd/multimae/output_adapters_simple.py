@@ -71,12 +71,24 @@ class SpatialOutputAdapter(nn.Module):
         x = ctx.float()
         if self.task_embeddings is not None and self.task in self.task_embeddings:
             x = x + self.task_embeddings[self.task].reshape(1, -1)
+        return self.decode_rows(x, B, P, seg, once, enc_rows.dtype)
+
+    def own_task_embedding(self):
+        """The task embedding forward adds to the projected context (None when the adapter has none for its task)."""
+        if self.task_embeddings is not None and self.task in self.task_embeddings:
+            return self.task_embeddings[self.task]
+        return None
+
+    def decode_rows(self, x: torch.Tensor, B: int, P: int, seg=None, once: bool = False, T=None) -> torch.Tensor:
+        """x (B*P, dim_tokens) fp32 = proj_context(encoder rows) + task embedding -> out_proj tokens.  MultiMAE's packed forward
+        computes every decoder's context projection in ONE GEMM (ops.kv_ctx_projections) and enters here."""
+        T = compute_dtype(self.out_proj.weight) if T is None else T
         delta = None
         if isinstance(self.decoder_transformer, nn.Sequential):
             for blk in self.decoder_transformer:
                 x, delta = blk.forward_rows(x, delta, B, P, seg, once)
         y = x if delta is None else x + delta.float()
-        return linear(wcast(y, enc_rows.dtype), self.out_proj.weight, self.out_proj.bias, once=once)
+        return linear(wcast(y, T), self.out_proj.weight, self.out_proj.bias, once=once)
 
     def forward(self, encoder_tokens: torch.Tensor, input_info: Dict, ids_keep: torch.Tensor = None,
                 ids_restore: torch.Tensor = None):

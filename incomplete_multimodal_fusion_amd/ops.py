@@ -289,6 +289,121 @@ def kv_q_projections(z, r0, n, wq, wkv):
     return _KvQ.apply(z, r0, n, wq, wkv)
 
 
+
+class _KvCtx(torch.autograd.Function):
+    """Pool K/V projection over ALL rows of z and the decoders' context projections over its LAST n rows in one node:
+    kv = z @ Wkv^T, ctx = z[r0:r0+n] @ cat(Wc_i)^T + cat(b_i).  One GEMM serves every decoder (their proj_context weights
+    row-concatenated: three N = 256 GEMMs become one N = 768), and the backward adds the context path into the tail rows
+    of dz in place -- autograd otherwise zero-fills a full-size gradient for the row slice and sums one (rows, D) tensor per
+    decoder.  The concatenated weights are assembled per call (they do not sit back to back in the flat buffer); their
+    gradients go back through autograd as row slices of one split-K result."""
+
+    @staticmethod
+    def forward(ctx, z, r0, n, wkv, nw, *wb):
+        from .engine import grad_view_of, shadow_of
+        T = z.dtype
+        ws, bs = wb[:nw], wb[nw:]
+
+        def cast(w):
+            c = shadow_of((w,), T)
+            return c if c is not None else (w if w.dtype == T else w.to(T))
+        wkv_c = cast(wkv)
+        wc = torch.cat([cast(w) for w in ws], dim=0)
+        bc = torch.cat([b if b.dtype == T else b.to(T) for b in bs], dim=0) if bs else None
+        with torch.autocast("cuda", enabled=False):
+            kv = torch.nn.functional.linear(z, wkv_c)
+            c = torch.nn.functional.linear(z[r0:r0 + n], wc, bc)
+        ctx.save_for_backward(z, wkv_c, wc)
+        ctx.wkv = wkv
+        ctx.cfg = (r0, n, nw, grad_view_of((wkv,)) if wkv.dtype == torch.float32 else None, wkv.dtype,
+                   [w.shape[0] for w in ws], [w.dtype for w in ws], [b.dtype for b in bs])
+        return kv, c
+
+    @staticmethod
+    def backward(ctx, gkv, gc):
+        z, wkv_c, wc = ctx.saved_tensors
+        r0, n, nw, gvkv, dkv_, sizes, wdt, bdt = ctx.cfg
+        gkv = gkv if gkv.is_contiguous() else gkv.contiguous()
+        gc = gc if gc.is_contiguous() else gc.contiguous()
+        with torch.autocast("cuda", enabled=False):
+            from .engine import shadow_t_of
+            gz = None
+            if ctx.needs_input_grad[0]:
+                wt = shadow_t_of((ctx.wkv,), wkv_c.dtype)
+                gz = torch.nn.functional.linear(gkv, wt if wt is not None else wkv_c.t().contiguous())
+                zs = gz[r0:r0 + n]
+                torch.addmm(zs, gc, wc, out=zs)
+            gwkv = _wgrad(gkv, z, gvkv)
+            gwc = _wgrad(gc, z[r0:r0 + n], None)
+            gb = colsum(gc) if bdt else None
+        gws, gbs, off = [], [], 0
+        for sz, dt_ in zip(sizes, wdt):
+            g = gwc[off:off + sz]
+            gws.append(g if g.dtype == dt_ else g.to(dt_))
+            off += sz
+        off = 0
+        for sz, dt_ in zip(sizes, bdt):
+            g = gb[off:off + sz]
+            gbs.append(g if g.dtype == dt_ else g.to(dt_))
+            off += sz
+        if gvkv is not None:
+            from .engine import grads_written_in_place
+            grads_written_in_place((ctx.wkv,))
+            gwkv = None
+        elif gwkv.dtype != dkv_:
+            gwkv = gwkv.to(dkv_)
+        return (gz, None, None, gwkv, None, *gws, *gbs)
+
+
+def kv_ctx_projections(z, r0, n, wkv, ctx_weights, ctx_biases):
+    """-> (kv over all rows of z, ctx over rows [r0, r0+n) with the row-concatenated `ctx_weights` (+ biases)).
+    wkv must be used once per step (see linear())."""
+    assert len(ctx_biases) in (0, len(ctx_weights))
+    return _KvCtx.apply(z, r0, n, wkv, len(ctx_weights), *ctx_weights, *ctx_biases)
+
+
+class _SplitColsF32(torch.autograd.Function):
+    """x (rows, sum widths) in the compute dtype -> one contiguous fp32 tensor per column block (+ an optional broadcast row
+    added to it).  The backward writes the blocks' gradients side by side into ONE (rows, sum widths) tensor of x's dtype
+    (autograd's own slice backward would zero-fill a full-width tensor per block and add them up)."""
+
+    @staticmethod
+    def forward(ctx, x, widths, *adds):
+        outs, off = [], 0
+        for w, a in zip(widths, adds):
+            o = x[:, off:off + w].to(torch.float32)
+            if a is not None:
+                if x.dtype != torch.float32:
+                    o += a.reshape(1, -1).float()                   # o is a fresh tensor (the cast made it)
+                else:
+                    o = o + a.reshape(1, -1).float()
+            outs.append(o.contiguous())
+            off += w
+        ctx.cfg = (x.dtype, tuple(widths), [None if a is None else (a.shape, a.dtype) for a in adds])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        xdt, widths, ameta = ctx.cfg
+        rows = next(g.shape[0] for g in gs if g is not None)
+        gx = torch.empty(rows, sum(widths), dtype=xdt, device=next(g.device for g in gs if g is not None))
+        gadds, off = [], 0
+        for w, g, am in zip(widths, gs, ameta):
+            if g is None:
+                gx[:, off:off + w].zero_()
+                gadds.append(None)
+            else:
+                gx[:, off:off + w].copy_(g)
+                gadds.append(None if am is None else colsum(g if g.is_contiguous() else g.contiguous()).to(am[1]).reshape(am[0]))
+            off += w
+        return (gx, None, *gadds)
+
+
+def split_cols_f32(x, widths, adds=None):
+    """-> list of fp32 (rows, w_i) tensors: x[:, block i] (+ adds[i] broadcast over the rows when given)."""
+    adds = [None] * len(widths) if adds is None else list(adds)
+    return list(_SplitColsF32.apply(x, tuple(widths), *adds))
+
 def linear(x, weight, bias=None, side_wgrad=False, once=False):
     """weight: one (N, K) master weight or a list of them (row-concatenated, e.g. [to_q.weight, to_kv.weight]).
     once: these weights are used exactly once per optimizer step -- their fp32 gradient may then be written straight
