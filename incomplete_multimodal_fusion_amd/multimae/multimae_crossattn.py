@@ -397,6 +397,11 @@ class MultiMAE(nn.Module):
                                 ops.split_cols_f32(ctx_all, [a.dim_tokens for a in ads], [a.own_task_embedding() for a in ads])))
         else:
             kvp = linear(tokens_T, ap.to_kv.weight, once=True)                                         # (BN+BP, 2I), context un-normalised
+        gk = None
+        if self.output_adapters is not None and self.has_contrastive_tokens:
+            # the contrastive queries' keys (:530-543) are a row gather of kvp; taken here, in one node with the pass-through that
+            # the pooling attention reads, so that kvp's two gradients are merged by a scatter-add instead of a full-size sum
+            kvp, gk = ops.fork_gather_rows(kvp, desc.tok_fus, filt=desc.tok_mod, nfilt=M)                  # (B*N, 2I)
         rq = linear(ops.layernorm(self.return_tokens[0].contiguous(), ap.norm.gamma, out_dtype=T), ap.to_q.weight)
         a = ops.mha_cross(rq.repeat(B, 1), kvp, Hh, dh, desc.pool_q, desc.enc_seg, ap.scale, empty_mode=0)
         pooled = linear(a, ap.to_out.weight).float()                                        # (B*R, D)
@@ -448,7 +453,6 @@ class MultiMAE(nn.Module):
         # ---- contrastive return tokens: one query per modality over the fusion tokens at its kept patches (:530-543) -----
         rt = torch.cat([getattr(self, 'return_token_' + d)[0] for d in doms], dim=0).contiguous()   # (M, D)
         cq = linear(ops.layernorm(rt, ap.norm.gamma, out_dtype=T), ap.to_q.weight)                  # (M, I)
-        gk = ops.gather_rows(kvp, desc.tok_fus, unique=False, filt=desc.tok_mod, nfilt=M)          # (B*N, 2I)
         a = ops.mha_cross(cq.repeat(B, 1), gk, Hh, dh, desc.ctr_q, desc.ctr_k, ap.scale, empty_mode=1)
         r = linear(a, ap.to_out.weight).float()                                             # (B*M, D)
         r = r + self.mlp(ops.layernorm(r, self.norm.gamma, out_dtype=T)).float()

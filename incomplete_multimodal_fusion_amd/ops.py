@@ -547,6 +547,8 @@ class _PartsAddLN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf, cfg, *xs):
         eps1, eps2, out_dtype, delta_off, y_row0, dual = cfg
+        ctx.set_materialize_grads(False)        # an unused output (a dropped alias, the last layer's residual) arrives as None,
+                                                # not as a zero-filled tensor of its size (18 fills per step at ViT-B)
         D = xs[0].shape[1]
         rows = [x.shape[0] for x in xs]
         total = sum(rows)
@@ -604,10 +606,16 @@ class _PartsAddLN(torch.autograd.Function):
         g1, b1, g2, gb1, gb2, stats, stats_b, *ln_in = ctx.saved_tensors
         rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2, has_out, y_row0, dual, y_given = ctx.meta
         grads = list(grads)
-        gyb = _c(grads.pop()) if dual is not None else None
-        gy = _c(grads[-1])
-        ups = list(grads[:-1])          # upstream grads of the x_new / alias outputs, in part order
-        dev = gy.device
+        gyb = grads.pop() if dual is not None else None
+        gy = grads[-1]
+        ups = list(grads[:-1])          # upstream grads of the x_new / alias outputs, in part order (None: unused output)
+        dev = stats.device
+        if gy is None:                  # the normalised matrix itself went unused (only the residual outputs were)
+            gy = torch.zeros(y_row0 + sum(rows), D, dtype=out_dtype, device=dev)
+        if dual is not None and gyb is None:
+            gyb = torch.zeros(dual[1] + rows[dual[0]], D, dtype=out_dtype, device=dev)
+        gy = _c(gy)
+        gyb = _c(gyb) if gyb is not None else None
         gdelta = torch.empty(dmeta[0], dtype=dmeta[1], device=dev) if dmeta is not None else None
         ddt = dt(dmeta[1]) if dmeta is not None else _lib.F32
         dbl = g2 is not None
@@ -846,6 +854,53 @@ class _GatherRows(torch.autograd.Function):
                 call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs),
                      gs.stride(0), 1, ptr(filt), f, stream())
         return gs, None, None, None, None
+
+
+class _ForkGatherRows(torch.autograd.Function):
+    """(src, gathered) with gathered[r] = src[idx[r]]: `src` handed through for its OTHER consumer plus the row gather, as one
+    node.  The backward scatter-ADDS the gathered rows' gradient into the gradient that came back through the pass-through
+    output, in place -- instead of scattering into a zero-filled full-size tensor that autograd then adds to the other one
+    (a fill and a three-operand pass over (rows, W) for a gather that touches a fraction of the rows)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, filt, nfilt):
+        assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
+        out = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+        call("mmae_gather_rows", dt(src), idx.numel(), src.shape[1], ptr(src), src.stride(0), ptr(idx), ptr(out),
+             out.stride(0), stream())
+        ctx.save_for_backward(idx, filt)
+        ctx.cfg = (src.shape, nfilt)
+        ctx.set_materialize_grads(False)
+        return src.view_as(src), out
+
+    @staticmethod
+    def backward(ctx, g_src, g):
+        idx, filt = ctx.saved_tensors
+        shape, nfilt = ctx.cfg
+        if g is None:
+            return g_src, None, None, None
+        g = _c(g)
+        if g_src is None:
+            gs, acc = torch.zeros(shape, dtype=g.dtype, device=g.device), 0
+        elif g_src.is_contiguous() and g_src._base is None and g_src.dtype == g.dtype:
+            gs, acc = g_src, 1              # produced for this node alone (its only consumer is the pass-through output)
+        else:
+            gs, acc = g_src.to(g.dtype).contiguous().clone(), 1
+        if filt is None:
+            call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs), gs.stride(0), acc, None, 0,
+                 stream())
+        else:
+            # destination rows repeat across filter classes (modalities) but are unique within one: one pass per class, each
+            # adding to what the earlier ones left
+            for f in range(nfilt):
+                call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs), gs.stride(0),
+                     1 if (acc or f > 0) else 0, ptr(filt), f, stream())
+        return gs, None, None, None
+
+
+def fork_gather_rows(src, idx, filt=None, nfilt=0):
+    """-> (src passed through, src[idx]); use the first result in place of `src` for its other consumer."""
+    return _ForkGatherRows.apply(src, idx, filt, nfilt)
 
 
 def gather_rows(src, idx, unique=True, filt=None, nfilt=0):

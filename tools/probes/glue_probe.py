@@ -30,7 +30,7 @@ def main():
         step(x)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         for _ in range(2):
             step(x)
         torch.cuda.synchronize()
@@ -47,13 +47,18 @@ def main():
             continue
         for k in ks:
             name = k.name
-            if name.startswith("Cijk") or name.startswith("Custom_Cijk") or "mmae" in name or name.startswith("_Z") and "at6native" not in name:
+            if name.startswith("Cijk") or name.startswith("Custom_Cijk") or "mmae" in name or (name.startswith("_Z") and "at6native" not in name and "colsum" not in name):
                 continue
-            if not ("at::native" in name or "rocclr" in name or "at6native" in name):
+            if not ("at::native" in name or "rocclr" in name or "at6native" in name or "colsum" in name or "splitk" in name):
                 continue
             short = name.split("<")[0][-40:] + ("<" + name.split("<")[1][:60] if "<" in name else "")
-            frames = [f for f in (e.stack or []) if "/repo/" in f or "incomplete_multimodal" in f or "bench.py" in f]
-            site = frames[0] if frames else "(no repo frame)"
+            # attribution: the chain of enclosing CPU ops (autograd nodes carry the Function's name), outermost first
+            chain, q = [], e
+            while q is not None:
+                chain.append(q.name)
+                q = q.cpu_parent
+            chain = [c for c in reversed(chain) if not c.startswith("ProfilerStep")]
+            site = " > ".join(chain[:3])
             small[short] += 1
             dur[short] += k.duration
             where[short][(e.name, site)] += 1
