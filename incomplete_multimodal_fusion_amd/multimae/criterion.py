@@ -70,17 +70,23 @@ def dino_loss_func(student_output, teacher_output, teacher_temp=0.04, student_te
 class HardNegtive_loss(nn.Module):         # criterion.py:214-268 (sic)
     def __init__(self, tau_plus=0.1, beta=1.0, temperature=0.5, alpha=256, estimator='hard'):
         super().__init__()
-        if estimator != 'hard':
-            raise Exception('Invalid estimator selected. Only the reference default "hard" is built.')
+        if estimator not in ('hard', 'easy'):
+            raise Exception('Invalid estimator selected. Please use any of [hard, easy]')          # criterion.py:259-260
         self.tau_plus, self.beta, self.temperature, self.estimator, self.alpha = tau_plus, beta, temperature, estimator, alpha
 
     def forward(self, out_1, out_2):
+        if self.estimator == 'easy':
+            # Ng = neg.sum(-1) (criterion.py:257-258) is the 'hard' expression at beta = 0 (unit importance weights) and
+            # tau_plus = 0; its clamp is then never active: every negative term is >= e^(-1/T), so their sum is >= N e^(-1/T)
+            return ops.hardneg_loss(out_1, out_2, 0.0, 0.0, self.temperature)
         return ops.hardneg_loss(out_1, out_2, self.tau_plus, self.beta, self.temperature)
 
 
 # Names the reference driver imports but never calls on this path (pretrain_mmae.py:37, :492, :497): plain torch.
-def byol_loss_func(p, z, simplified=True):
-    return 2 - 2 * F.cosine_similarity(p, z.detach(), dim=-1).mean()
+def byol_loss_func(p, z, simplified=True):                                                  # criterion.py:319-326
+    if simplified:
+        return 2 - 2 * F.cosine_similarity(p, z.detach(), dim=-1).mean()
+    return 2 - 2 * (F.normalize(p, dim=1) * F.normalize(z, dim=1).detach()).sum(dim=1).mean()
 
 
 def vicreg(repr_a, repr_b, l=25, mu=25, nu=1):

@@ -227,6 +227,28 @@ def gen_ops(ref):
     g1, g2 = grads_of(l, torch.tensor(1.0), [o1, o2])
     bag.put("hardneg", out_1=o1, out_2=o2, loss=l, g1=g1, g2=g2)
 
+    # the rarely used siblings on the SAME inputs (no new draws from the global RNG: the fixtures after this one keep their seeds):
+    # HardNegtive_loss(estimator='easy') (criterion.py:257-258), vicreg (:175-212), byol_loss_func (:319-326)
+    hn_e = ref.cr.HardNegtive_loss(estimator='easy')
+    a = o1.detach().clone().requires_grad_(); b = o2.detach().clone().requires_grad_()
+    torch.Tensor.cuda = lambda self, *a_, **k: self
+    try:
+        le = hn_e(a, b)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    ge1, ge2 = grads_of(le, torch.tensor(1.0), [a, b])
+    bag.put("hardneg_easy", loss=le, g1=ge1, g2=ge2)
+    a = o1.detach().clone().requires_grad_(); b = o2.detach().clone().requires_grad_()
+    lv = ref.cr.vicreg(a, b)
+    gv1, gv2 = grads_of(lv, torch.tensor(1.0), [a, b])
+    bag.put("vicreg", loss=lv, g1=gv1, g2=gv2)
+    a = o1.detach().clone().requires_grad_(); b = o2.detach().clone().requires_grad_()
+    lb = ref.cr.byol_loss_func(a, b)
+    (gb1,) = grads_of(lb, torch.tensor(1.0), [a])
+    lb_full = ref.cr.byol_loss_func(a, b, simplified=False)
+    (gb1f,) = grads_of(lb_full, torch.tensor(1.0), [a])
+    bag.put("byol", loss=lb, gp=gb1, loss_full=lb_full, gp_full=gb1f)
+
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **bag)
     print("ops.npz:", len(bag), "arrays")
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mmae_oracle as O
-from tests.test_gpu_kernels import DEV, close, dense_attention_ref
+from tests.test_gpu_kernels import COLSUM, DEV, GRAD, close, dense_attention_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -60,9 +60,9 @@ def test_fuzz_attention_segments(T, variant):
         gq = q64.grad if q64.grad is not None else torch.zeros_like(q64)
         gk = k64.grad if k64.grad is not None else torch.zeros_like(k64)
         gv = v64.grad if v64.grad is not None else torch.zeros_like(v64)
-        close(qd.grad[qmask.to(DEV)], gq.reshape(nq, I)[qmask], tol * 2, "dq " + tag)
-        close(kvd.grad[:, :I], gk.reshape(nk, I), tol * 2, "dk " + tag)
-        close(kvd.grad[:, I:], gv.reshape(nk, I), tol * 2, "dv " + tag)
+        close(qd.grad[qmask.to(DEV)], gq.reshape(nq, I)[qmask], tol * GRAD, "dq " + tag)
+        close(kvd.grad[:, :I], gk.reshape(nk, I), tol * GRAD, "dk " + tag)
+        close(kvd.grad[:, I:], gv.reshape(nk, I), tol * GRAD, "dv " + tag)
 
 
 def test_fuzz_masks_from_draws_bit_exact():
@@ -134,11 +134,11 @@ def test_fuzz_add_double_layernorm_parts(T):
             close(a, b, 2e-5 if T == torch.float32 else 4e-3, "x_new " + tag)
         for a, b in zip(xd, x64):
             if b.shape[0]:
-                close(a.grad, b.grad, tol * 2, "gx " + tag)
-        close(dd.grad, d64.grad, tol * 2, "gdelta " + tag)
+                close(a.grad, b.grad, tol * GRAD, "gx " + tag)
+        close(dd.grad, d64.grad, tol * GRAD, "gdelta " + tag)
         for a, b, nm in zip(pg, r64, ("g1", "b1", "g2", "b2")):
             if a is not None:
-                close(a.grad, b.grad, tol * 4, nm + " " + tag)
+                close(a.grad, b.grad, tol * COLSUM, nm + " " + tag)
 
 
 def test_fuzz_masked_losses_and_patchify():
