@@ -238,16 +238,16 @@ def mfma_busy():
 def event_bracket_overhead_ms(device, n=96):
     """What a HIP-event bracket measures around NOTHING on a busy stream: the two event packets are each processed after
     the preceding work drains, so every bracket of ops.KernelTimer carries this constant on top of the kernel's own
-    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms elementwise kernel of
-    the library (mmae_gelu_fwd over 128 Mi bf16 elements; not a GEMM: TunableOp would tune the new shape) keeps the queue
-    busy, then an empty bracket -- and subtracted from the roofline legs' averages; both figures are printed.  (In a rocprofv3
-    summary of bench.py these n launches show up as `gelu_fwd_kernel` calls of ~85 us outside every timed step.)"""
+    duration (rocprofv3's kernel-trace duration has no such term).  Calibrated in place -- a ~0.1 ms streaming copy of the
+    library (mmae_debug_stream_copy, 256 MiB; not a GEMM: TunableOp would tune the new shape) keeps the queue busy, then an
+    empty bracket -- and subtracted from the roofline legs' averages; both figures are printed.  (In a rocprofv3 summary of
+    bench.py these n launches are the `calib_copy_kernel` row, outside every timed step.)"""
     from incomplete_multimodal_fusion_amd._lib import call, ptr, stream
-    a = torch.zeros(128 << 20, device=device, dtype=torch.bfloat16)
+    a = torch.zeros(256 << 20, device=device, dtype=torch.uint8)
     b = torch.empty_like(a)
     pairs = []
     for _ in range(n):
-        call("mmae_gelu_fwd", 1, a.numel(), ptr(a), ptr(b), stream())
+        call("mmae_debug_stream_copy", a.numel(), ptr(a), ptr(b), stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()
         pairs.append((e0, e1))
@@ -566,10 +566,10 @@ def main():
             "ranks": world, "backend": (dist.get_backend() if distributed else "none"),
             # dominant hand-written kernel by total time (profiles/rNN_kernel_stats.md): the fused residual-add +
             # double-LayerNorm backward, HBM-bound.  achieved = algorithmic bytes of the launch / its HIP-event time.
-            "roofline": {"kernel": "add_ln_bwd_kernel<bf16,bf16,3,double,nobeta>" if not args.fp32 else "add_ln_bwd_kernel<f32,...>",
+            "roofline": {"kernel": "add_ln_bwd_fast_kernel<bf16,bf16,3,double,up,gx,gdelta>" if not args.fp32 else "add_ln_bwd_fast_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("add_ln_bwd_kernel") if (not args.fp32 and args.batch == 256 and default_doms) else None,
+                         "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (not args.fp32 and args.batch == 256 and default_doms) else None,
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n},

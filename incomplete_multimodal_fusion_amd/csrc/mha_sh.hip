@@ -316,10 +316,14 @@ __device__ __forceinline__ void sh_zero_rows(const MhaDesc& p, long row0, int n,
 // are covered by the others without hand-interleaving (the first version of this kernel -- 8 waves with both slots in every
 // wave, 212 VGPRs, two waves per SIMD running the same code in lock-step -- measured 230-240 us at the bench shape with
 // 41 % of wave cycles parked and 22 % issue-stalled: no faster than the tile-per-block kernel).
-// TPB = key tiles per workgroup barrier.  2: the loop body runs twice behind one s_barrier -- half the barriers, half the points
+// VAR 1: two key tiles per workgroup barrier -- the loop body runs twice behind one s_barrier: half the barriers, half the points
 // at which 16 waves wait for the slowest one (a slot switch, a finish, a loader still issuing); the ring then holds the pair
 // being consumed and the pair in flight (4 stages, tiles issued one pair-iteration ahead of their use).
-template <int MODE, int TPB>
+// VAR 2: the 16 ring pieces of a tile are issued by FOUR loader waves (12-15: K pieces 0-3 / 4-7, V pieces 0-3 / 4-7), every step,
+// instead of one rotating wave issuing all 16 every fourth step: an LDS-DMA instruction costs its issuer ~230 cycles, so the lone
+// loader needs ~3.7 k cycles for a tile -- most of a step -- and when it also holds queries (rows 128-255 of a segment: every
+// ragged split) its step runs long and the whole workgroup waits for it at the next barrier.
+template <int MODE, int VAR>
 __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     __shared__ __attribute__((aligned(1024))) bf16 ringK[SH_NS][4096];
     __shared__ __attribute__((aligned(1024))) bf16 ringV[SH_NS][4096];
@@ -392,8 +396,21 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     // loader waits for the step's pieces (vmcnt) before the barrier.
     int lt = 0, lh = 0, lpt = npass * ntile;                        // tile / head of ring step `lj`, tiles left in that head
     int lj = 0, lstage = 0, myseq = 0;
+    int q0 = 0, q1 = 0, q2 = 0, nfl = 0;                            // VAR 2: sequence numbers of my pieces of the (up to three) tiles in flight
     auto issue_ring = [&]() {                                       // every wave advances the position; the step's loader issues
-        if (MODE != 2 && wave == 12 + (lj & 3)) {
+        if (VAR == 2) {
+            if (MODE != 2 && wave >= 12) {
+                const long row0 = t_row(lt); const int n = t_info(lt) & 255;
+                const bool isv = wave >= 14;
+                const bf16* b_ = (isv ? vg + row0 * p.v_stride : kg + row0 * p.k_stride) + (h0 + lh) * 64;
+                bf16* dst = isv ? &ringV[lstage][0] : &ringK[lstage][0];
+                const int pc0 = 4 * (wave & 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sh_dma(b_, n, kvsb, kvoff ^ (16 * (j & 1)), 8 * (pc0 + j) * kvsb, dst + (pc0 + j) * 512);
+                vm += 4;
+            }
+            q0 = q1; q1 = q2; q2 = vm; ++nfl;
+        } else if (MODE != 2 && wave == 12 + (lj & 3)) {
             const long row0 = t_row(lt); const int n = t_info(lt) & 255;
             const bf16* kb_ = kg + row0 * p.k_stride + (h0 + lh) * 64;
             const bf16* vb_ = vg + row0 * p.v_stride + (h0 + lh) * 64;
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     find_next(0, 0, 0);
     if (nh >= 0) issue_q(nsg, chunk_of(np_), h0 + nh);
     mark = vm;
-    for (int i = 0; i < (TPB == 2 ? SH_NS : SH_D) && i < G; ++i) issue_ring();
+    for (int i = 0; i < (VAR == 1 ? SH_NS : SH_D) && i < G; ++i) issue_ring();
 
     bool act = false, fresh = false;
     int t = 0, pi = 0, hi = 0;
@@ -476,13 +493,14 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     if (ST) { tl = sh_now(); t_loop = tl; }
     int stage = 0;                                                  // ring stage of tile g
     for (int g = 0; g < G; ++g) {
-        if (TPB == 1 || (g & 1) == 0) {
-            if (wave == 12 + (g & 3)) sh_wait_vm(vm - myseq);     // the pieces of tile g were mine to fetch
-            if (TPB == 2 && g + 1 < G && wave == 12 + ((g + 1) & 3)) sh_wait_vm(vm - myseq);
+        if (VAR != 1 || (g & 1) == 0) {
+            if (VAR == 2) { if (wave >= 12) sh_wait_vm(vm - (nfl >= 3 ? q0 : nfl == 2 ? q1 : q2)); --nfl; }     // my four pieces of tile g: the oldest in flight
+            else if (wave == 12 + (g & 3)) sh_wait_vm(vm - myseq);     // the pieces of tile g were mine to fetch
+            if (VAR == 1 && g + 1 < G && wave == 12 + ((g + 1) & 3)) sh_wait_vm(vm - myseq);
             SH_T(0);
             __builtin_amdgcn_s_barrier();
             SH_T(1);
-            if (TPB == 1) { if (lj < G) issue_ring(); }
+            if (VAR != 1) { if (lj < G) issue_ring(); }
             else if (g >= 2) { if (lj < G) issue_ring(); if (lj < G) issue_ring(); }   // into the stages of the pair just finished
         }
         const int tinf = t_info(t), kn = tinf & 255, sg = (tinf >> 8) & 255, fl = tinf >> 16;
@@ -1112,17 +1130,19 @@ int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
     if (d.max_k_rows / 64 + d.nseg > SH_MAXT || d.k_stride != d.v_stride || d.nseg > MAXSEG) return MMAE_ERR_ARG;
     const int hpb = sh_heads_per_block(d.B, d.H);
     const dim3 grid(d.B * (d.H / hpb)), blk(1024);
-    if (mode == 1) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 1>), grid, blk, 0, st, d, hpb);
-    else if (mode == 2) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 1>), grid, blk, 0, st, d, hpb);
+    if (mode == 1) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 0>), grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 0>), grid, blk, 0, st, d, hpb);
 #if MMAE_DIAG
-    else if (mode == 3) MMAE_LAUNCH((mha_sh_fwd_kernel<3, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 3) MMAE_LAUNCH((mha_sh_fwd_kernel<3, 0>), grid, blk, 0, st, d, hpb);
 #else
     else if (mode == 3) return MMAE_ERR_ARG;
 #endif
-    else if (mode == 10) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 2>), grid, blk, 0, st, d, hpb);     // two tiles per barrier
-    else if (mode == 11) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 2>), grid, blk, 0, st, d, hpb);
-    else if (mode == 12) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 2>), grid, blk, 0, st, d, hpb);
-    else MMAE_LAUNCH((mha_sh_fwd_kernel<0, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 10) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 1>), grid, blk, 0, st, d, hpb);     // two tiles per barrier
+    else if (mode == 11) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 12) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 20) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 2>), grid, blk, 0, st, d, hpb);     // four loader waves
+    else if (mode == 21) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 2>), grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH((mha_sh_fwd_kernel<0, 0>), grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

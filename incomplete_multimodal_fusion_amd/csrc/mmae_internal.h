@@ -25,6 +25,8 @@ int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const 
 int mmae_debug_mha_stamps(unsigned long long* host8);
 /* diagnostic (variant 8 of the forward, mha_sh.hip): 2 x 16 stamp sums (global-role waves, local-role waves), cleared on read */
 int mmae_debug_sh_stamps(unsigned long long* host32);
+/* bench.py's event-bracket calibration: a streaming copy of n_bytes (multiple of 16) under its own kernel name. */
+int mmae_debug_stream_copy(long n_bytes, const void* src, void* dst, void* stream);
 #ifdef __cplusplus
 }
 #endif

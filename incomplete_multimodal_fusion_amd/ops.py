@@ -655,8 +655,10 @@ class _PartsAddLN(torch.autograd.Function):
                 r0 += n
                 continue
             tm = _TIMERS.get("mmae_add_ln_bwd")
-            if tm is not None and not (dbl and not has_b1 and out_dtype == torch.bfloat16 and D == 768 and ddt == _lib.BF16):
-                tm = None       # time one template instance only: <bf16, bf16, 3, double, no beta> (the encoder's)
+            if tm is not None and not (dbl and not has_b1 and out_dtype == torch.bfloat16 and D == 768 and ddt == _lib.BF16 and
+                                       up is not None and gx is not None and off >= 0):
+                tm = None       # time ONE template instance only: add_ln_bwd_fast_kernel<bf16, bf16, 3, double, up, gx, gdelta>
+                                # (the encoder's residual passes: 59 of the 72 launches of this entry point per step at ViT-B)
             if tm is not None:
                 # algorithmic bytes: x_new (4) + gy + [gx_up (4)] read, [gx (4)] + [gdelta] written, per element
                 per = 4 + gy.element_size() + (4 if up is not None else 0) + (4 if gx is not None else 0) + \
