@@ -68,6 +68,13 @@ int mmae_modattn_bwd_nsplit(int B);
 int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, const float* x, const void* delta, float* x_new,
                     void* y, const float* gamma1, const float* beta1, float eps1, const float* gamma2,
                     const float* beta2, float eps2, float* stats, void* stream);
+/* The same pass with an fp32 y AND its bf16 copy y_bf16: the final norm (MM/multimae_crossattn.py:472), whose fp32 output the
+ * model returns (ori_tokens / enc_fus, :495, :504) while the attention pool and the decoders consume it in the compute dtype
+ * (the cast an autocast-ed nn.Linear applies to its input, :475-527).  Bias-less LayerNorms of width 768 / 1024 only
+ * (MMAE_ERR_ARG otherwise: the caller casts separately). */
+int mmae_add_ln_fwd_cast(int dtype_delta, long rows, int D, const float* x, const void* delta, float* x_new, float* y,
+                         void* y_bf16, const float* gamma1, float eps1, const float* gamma2, float eps2, float* stats,
+                         void* stream);
 /* gx = LN-backward(gy) + gx_up (optional); written as fp32 (gx) and/or dtype_delta (gdelta).  Column sums
  * dgamma1/2, dbeta1/2 (fp32, D; += when accumulate != 0) via workspace ws of mmae_add_ln_bwd_ws_floats(rows, D) floats. */
 int mmae_add_ln_bwd_ws_floats(long rows, int D);

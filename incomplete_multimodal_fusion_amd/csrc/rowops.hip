@@ -46,6 +46,7 @@ struct AddLnFwd {
     const float* x; const void* delta; float* x_new; void* y;
     const float* g1; const float* b1; const float* g2; const float* b2;
     float eps1, eps2; float* stats; long rows; int D;
+    void* y2 = nullptr;          // fast path only: a bf16 copy of an fp32 y, written in the same pass (mmae_add_ln_fwd_cast)
 };
 
 // NC = number of 256-column chunks held per lane (4 columns per lane per chunk)
@@ -499,7 +500,7 @@ __device__ __forceinline__ float wave_sum_v(float v) {
     return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
-template <typename TD, typename TY, int NC, bool DOUBLE, bool HAS_DELTA>
+template <typename TD, typename TY, int NC, bool DOUBLE, bool HAS_DELTA, bool Y2 = false>
 __global__ __launch_bounds__(256) void add_ln_fwd_fast_kernel(AddLnFwd p) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -543,7 +544,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_fast_kernel(AddLnFwd p) {
         for (int c = 0; c < NC; ++c) v[c] = v[c] * r2 * G2[c];
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) st4s<TY>(reinterpret_cast<TY*>(p.y) + at + 256 * c, v[c]);
+    for (int c = 0; c < NC; ++c) {
+        st4s<TY>(reinterpret_cast<TY*>(p.y) + at + 256 * c, v[c]);
+        if (Y2) st4s<bf16>(reinterpret_cast<bf16*>(p.y2) + at + 256 * c, v[c]);
+    }
     if (lane == 0) *reinterpret_cast<f32x4*>(p.stats + row * 4) = f32x4{m1, r1, m2, r2};
 }
 
@@ -789,6 +793,21 @@ template <typename K> static int resident_blocks(K kernel, int fallback) {
 // ---- dispatch of the fast paths: widths 768 (ViT-B) and 1024 (ViT-L); every other width runs the generic kernels
 static bool ln_fast_width(int D) { return D == 768 || D == 1024; }
 
+template <typename TD, int NC>
+static int add_ln_fwd_cast_t(const AddLnFwd& p, hipStream_t st) {
+    dim3 grid(cdiv(p.rows, 4)), blk(256);
+    const bool dbl = p.g2 != nullptr;
+    if (p.delta) {
+        if (dbl) MMAE_LAUNCH((add_ln_fwd_fast_kernel<TD, float, NC, true, true, true>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((add_ln_fwd_fast_kernel<TD, float, NC, false, true, true>), grid, blk, 0, st, p);
+    } else {
+        if (dbl) MMAE_LAUNCH((add_ln_fwd_fast_kernel<bf16, float, NC, true, false, true>), grid, blk, 0, st, p);
+        else MMAE_LAUNCH((add_ln_fwd_fast_kernel<bf16, float, NC, false, false, true>), grid, blk, 0, st, p);
+    }
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
 template <typename TD, typename TY, int NC>
 static int add_ln_fwd_fast_t(const AddLnFwd& p, hipStream_t st) {
     dim3 grid(cdiv(p.rows, 4)), blk(256);
@@ -902,6 +921,19 @@ extern "C" int mmae_add_ln_fwd(int dtype_delta, int dtype_y, long rows, int D, c
     const bool dbl = gamma2 != nullptr;
     if (ln_fast_width(D) && !beta1 && !beta2) return add_ln_fwd_fast(dtype_delta, dtype_y, p, reinterpret_cast<hipStream_t>(stream));
     return DISPATCH_TD_TY(add_ln_fwd_nc, p, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmae_add_ln_fwd_cast(int dtype_delta, long rows, int D, const float* x, const void* delta, float* x_new, float* y,
+                                    void* y_bf16, const float* gamma1, float eps1, const float* gamma2, float eps2, float* stats,
+                                    void* stream) {
+    if (!ok_dtype(dtype_delta) || rows < 0 || !ln_fast_width(D)) return MMAE_ERR_ARG;
+    if (!x || !y || !y_bf16 || !gamma1 || !stats || (delta && !x_new)) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    AddLnFwd p{x, delta, delta ? x_new : nullptr, y, gamma1, nullptr, gamma2, nullptr, eps1, eps2, stats, rows, D};
+    p.y2 = y_bf16;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype_delta == MMAE_BF16) return D == 768 ? add_ln_fwd_cast_t<bf16, 3>(p, st) : add_ln_fwd_cast_t<bf16, 4>(p, st);
+    return D == 768 ? add_ln_fwd_cast_t<float, 3>(p, st) : add_ln_fwd_cast_t<float, 4>(p, st);
 }
 
 extern "C" int mmae_add_ln_bwd_ws_floats(long rows, int D) {

@@ -377,10 +377,14 @@ class MultiMAE(nn.Module):
 
         # ---- final norm (:472) -------------------------------------------------------------------------------------------
         dl, o1, o2 = one_delta(dm, dm_off, df, df_off)
-        (xm, xf), tokens = ops.parts_add_ln([xm, xf], dl, [o1, o2], self.norm.gamma, None, out_dtype=torch.float32)
+        # fp32 tokens (returned: ori_tokens / enc_fus) and, under autocast, their bf16 copy for the pool / decoder projections from
+        # the same pass over the residual (the copy's gradient then reaches the LayerNorm backward in bf16: no cast either way)
+        res = ops.parts_add_ln([xm, xf], dl, [o1, o2], self.norm.gamma, None, out_dtype=torch.float32,
+                               cast_copy=(T == torch.bfloat16))
+        (xm, xf), tokens = res[0], res[1]
         ori_tokens = tokens[:BN].reshape(B, N, D)                                           # :495
         enc_fus = tokens[BN:].reshape(B, P, D)                                              # :504
-        tokens_T = wcast(tokens, T)
+        tokens_T = res[2] if len(res) == 3 else wcast(tokens, T)
 
         # ---- attention pooling into the return tokens (:475-497) ---------------------------------------------------------
         ap = self.attn_pool

@@ -546,7 +546,7 @@ class _PartsAddLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf, cfg, *xs):
-        eps1, eps2, out_dtype, delta_off, y_row0, dual = cfg
+        eps1, eps2, out_dtype, delta_off, y_row0, dual, cast_copy = cfg
         ctx.set_materialize_grads(False)        # an unused output (a dropped alias, the last layer's residual) arrives as None,
                                                 # not as a zero-filled tensor of its size (18 fills per step at ViT-B)
         D = xs[0].shape[1]
@@ -567,6 +567,10 @@ class _PartsAddLN(torch.autograd.Function):
         else:
             stats_b = None
         stats = torch.empty(total, 4, dtype=torch.float32, device=dev)
+        y2 = None
+        if cast_copy:                       # fp32 y plus its bf16 copy from the same pass (mmae_add_ln_fwd_cast)
+            assert out_dtype == torch.float32 and dual is None and b1 is None and b2 is None and y_buf is None and D in (768, 1024)
+            y2 = torch.empty(total, D, dtype=torch.bfloat16, device=dev)
         ln_in, outs = [], []
         r0 = 0
         ddt = dt(delta) if delta is not None else _lib.F32
@@ -590,6 +594,9 @@ class _PartsAddLN(torch.autograd.Function):
                     call("mmae_add_ln_fwd_dual", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
                          yp, ctypes.c_void_p(yb_buf.data_ptr() + dual[1] * D * esz), ptr(g1), ptr(g2), ptr(gb1), ptr(gb2),
                          eps1, eps2, sp, ptr(stats_b), stream())
+                elif cast_copy:
+                    call("mmae_add_ln_fwd_cast", ddt, x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None, yp,
+                         ctypes.c_void_p(y2.data_ptr() + r0 * D * 2), ptr(g1), eps1, ptr(g2), eps2, sp, stream())
                 else:
                     call("mmae_add_ln_fwd", ddt, dt(out_dtype), x.shape[0], D, ptr(x), dptr, ptr(xn) if off >= 0 else None,
                          yp, ptr(g1), ptr(b1), eps1, ptr(g2), ptr(b2), eps2, sp, stream())
@@ -598,15 +605,25 @@ class _PartsAddLN(torch.autograd.Function):
         ctx.save_for_backward(g1, b1, g2, gb1, gb2, stats, stats_b, *ln_in)
         ctx.meta = (rows, D, delta_off, out_dtype, None if delta is None else (delta.shape, delta.dtype),
                     b1 is not None, b2 is not None, [off >= 0 or x.requires_grad for x, off in zip(xs, delta_off)],
-                    y_row0, dual, y_buf is not None)
+                    y_row0, dual, y_buf is not None, cast_copy)
+        if cast_copy:
+            return (*outs, y, y2)
         return (*outs, y) if dual is None else (*outs, y, yb_buf)
 
     @staticmethod
     def backward(ctx, *grads):
         g1, b1, g2, gb1, gb2, stats, stats_b, *ln_in = ctx.saved_tensors
-        rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2, has_out, y_row0, dual, y_given = ctx.meta
+        rows, D, delta_off, out_dtype, dmeta, has_b1, has_b2, has_out, y_row0, dual, y_given, cast_copy = ctx.meta
         grads = list(grads)
         gyb = grads.pop() if dual is not None else None
+        if cast_copy:
+            # two gradients of the same values: through the fp32 matrix and through its bf16 copy.  Usually only the copy has
+            # consumers (pool / decoder projections): its gradient then IS gy, read by the kernel in bf16 -- no cast back
+            gy2 = grads.pop()
+            if grads[-1] is None and gy2 is not None:
+                grads[-1], out_dtype = gy2, torch.bfloat16
+            elif gy2 is not None:
+                grads[-1] = grads[-1] + gy2.float()
         gy = grads[-1]
         ups = list(grads[:-1])          # upstream grads of the x_new / alias outputs, in part order (None: unused output)
         dev = stats.device
@@ -680,18 +697,24 @@ class _PartsAddLN(torch.autograd.Function):
 
 
 def parts_add_ln(xs: List[torch.Tensor], delta: Optional[torch.Tensor], delta_off: List[int], g1, b1=None, g2=None,
-                 b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32, y_into=None, dual=None):
+                 b2=None, eps1=1e-5, eps2=1e-5, out_dtype=torch.float32, y_into=None, dual=None, cast_copy=False):
     """-> (list of updated residual parts, y).  A part with delta_off < 0 keeps its residual unchanged.
     y_into = (matrix, row0): y is written into rows [row0, ...) of `matrix` (returned in its place).
     dual = (part index, gamma1_b, gamma2_b, matrix_b, row0_b): that part is also normalised with the second gamma pair into
-    `matrix_b` in the same pass; the call then returns (parts, y, matrix_b)."""
+    `matrix_b` in the same pass; the call then returns (parts, y, matrix_b).
+    cast_copy (fp32 y, bias-less, width 768 / 1024; ignored otherwise -- the caller checks the length of the result): the
+    kernel also writes a bf16 copy of y; the call returns (parts, y, y_bf16)."""
     y_buf, y_row0 = (None, 0) if y_into is None else y_into
     gb1, gb2, yb_buf, dcfg = (None, None, None, None) if dual is None else (dual[1], dual[2], dual[3], (dual[0], dual[4]))
+    cast_copy = bool(cast_copy) and out_dtype == torch.float32 and dual is None and y_into is None and b1 is None and b2 is None \
+        and xs[0].shape[1] in (768, 1024)
     outs = list(_PartsAddLN.apply(delta, g1, b1, g2, b2, gb1, gb2, y_buf, yb_buf,
-                                  (eps1, eps2, out_dtype, tuple(delta_off), y_row0, dcfg), *xs))
-    yb = outs.pop() if dual is not None else None
+                                  (eps1, eps2, out_dtype, tuple(delta_off), y_row0, dcfg, cast_copy), *xs))
+    yb = outs.pop() if (dual is not None or cast_copy) else None
     y = outs.pop()
     x_news = [outs.pop(0) if (off >= 0 or x.requires_grad) else x for x, off in zip(xs, delta_off)]
+    if cast_copy:
+        return x_news, y, yb                    # yb: the bf16 copy of the fp32 y
     return (x_news, y) if dual is None else (x_news, y, yb)
 
 
