@@ -22,7 +22,7 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 2   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h */
+#define MMAE_ABI_VERSION 3   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);

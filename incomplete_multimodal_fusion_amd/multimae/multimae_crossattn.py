@@ -34,6 +34,7 @@ from .zorro_utils import (Attention, Block, Block_Fusion, LayerNorm, Mlp, TokenT
 __all__ = ['pretrain_multimae_tiny', 'pretrain_multimae_base', 'pretrain_multimae_large', 'MultiMAE']
 
 
+FUSED_FINAL_CAST = os.environ.get('MMAE_FUSED_CAST', '1') != '0'    # A/B knob: bf16 copy of the final norm's output from the same pass
 FUSED_DECODER_CTX = os.environ.get('MMAE_FUSED_CTX', '1') != '0'   # A/B knob: one GEMM for every decoder's proj_context
 
 class PredTokens:
@@ -380,7 +381,7 @@ class MultiMAE(nn.Module):
         # fp32 tokens (returned: ori_tokens / enc_fus) and, under autocast, their bf16 copy for the pool / decoder projections from
         # the same pass over the residual (the copy's gradient then reaches the LayerNorm backward in bf16: no cast either way)
         res = ops.parts_add_ln([xm, xf], dl, [o1, o2], self.norm.gamma, None, out_dtype=torch.float32,
-                               cast_copy=(T == torch.bfloat16))
+                               cast_copy=(T == torch.bfloat16 and FUSED_FINAL_CAST))
         (xm, xf), tokens = res[0], res[1]
         ori_tokens = tokens[:BN].reshape(B, N, D)                                           # :495
         enc_fus = tokens[BN:].reshape(B, P, D)                                              # :504
