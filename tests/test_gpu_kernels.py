@@ -381,6 +381,107 @@ def test_add_double_ln_vs_oracle(D, T):
     close(G1.grad, A.grad, tol * COLSUM, "dgamma1"); close(G2.grad, Bg.grad, tol * COLSUM, "dgamma2")
 
 
+@pytest.mark.parametrize("D", [768, 1024])
+@pytest.mark.parametrize("dbl", [False, True])
+def test_add_ln_with_bf16_copy_vs_oracle(D, dbl):
+    """mmae_add_ln_fwd_cast (the final norm, multimae_crossattn.py:472): fp32 y and its bf16 copy from one pass; the backward takes
+    the copy's bf16 gradient alone, the fp32 gradient alone, or both."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(11)
+    r1, r2 = 70, 201
+    x1 = torch.randn(r1, D); x2 = torch.randn(r2, D) * 2 - 1
+    delta = torch.randn(r1 + r2, D).to(torch.bfloat16)
+    g1 = torch.rand(D) + 0.5; g2 = (torch.rand(D) + 0.5) if dbl else None
+    gy32 = torch.randn(r1 + r2, D); gyT = torch.randn(r1 + r2, D).to(torch.bfloat16)
+    for use32, useT in ((False, True), (True, False), (True, True)):
+        xs = [x1.to(DEV).requires_grad_(), x2.to(DEV).requires_grad_()]
+        dd = delta.to(DEV).requires_grad_(); G1 = g1.to(DEV).requires_grad_()
+        G2 = g2.to(DEV).requires_grad_() if dbl else None
+        res = ops.parts_add_ln(xs, dd, [0, r1], G1, None, G2, None, out_dtype=torch.float32, cast_copy=True)
+        assert len(res) == 3 and res[2].dtype == torch.bfloat16
+        (n1, n2), y, yT = res
+        assert torch.equal(yT, y.to(torch.bfloat16)), "the copy must be the rounded fp32 output"
+        loss = 0
+        if use32:
+            loss = loss + (y * gy32.to(DEV)).sum()
+        if useT:
+            loss = loss + (yT.float() * gyT.to(DEV).float()).sum()
+        loss.backward()
+        X = torch.cat([x1, x2]).double().requires_grad_(); Dl = delta.double().requires_grad_()
+        A = g1.double().requires_grad_(); Bg = g2.double().requires_grad_() if dbl else None
+        xn = X + Dl
+        yr = O.zorro_layernorm(xn, A)
+        if dbl:
+            yr = O.zorro_layernorm(yr, Bg)
+        gtot = (gy32.double() if use32 else 0) + (gyT.double() if useT else 0)
+        (yr * gtot).sum().backward()
+        tag = "fp32 %s bf16 %s" % (use32, useT)
+        close(y, yr, 2e-5, "y " + tag); close(torch.cat([n1, n2]), xn, 1e-6, "x_new " + tag)
+        # the bf16-only case reads the gradient in bf16 (exact: it IS bf16); the mixed one sums in fp32 first
+        close(torch.cat([xs[0].grad, xs[1].grad]), X.grad, 2e-5 * GRAD, "gx " + tag)
+        close(dd.grad, Dl.grad, 1e-2 * GRAD, "gdelta " + tag)
+        close(G1.grad, A.grad, 2e-5 * COLSUM, "dgamma1 " + tag)
+        if dbl:
+            close(G2.grad, Bg.grad, 2e-5 * COLSUM, "dgamma2 " + tag)
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+def test_decoder_front_end_nodes_vs_torch(T):
+    """ops.kv_ctx_projections (pool K/V over all rows + every decoder's proj_context over the tail rows, one node),
+    ops.split_cols_f32 (column blocks + task embeddings) and ops.fork_gather_rows (pass-through + row gather, gradients merged
+    by scatter-add) against the plain torch compositions they replace (multimae_crossattn.py:475-543,
+    output_adapters_simple.py:166-176)."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(5)
+    rows, r0, D, I2 = 96, 40, 64, 48
+    n = rows - r0
+    z = torch.randn(rows, D).to(T)
+    wkv = torch.randn(I2, D) * 0.2
+    wcs = [torch.randn(16, D) * 0.2 for _ in range(3)]; bcs = [torch.randn(16) for _ in range(3)]
+    embs = [torch.randn(1, 1, 16), None, torch.randn(1, 1, 16)]
+    idx = torch.tensor([5, 17, 5, 80, -1, 33, 17, 2], dtype=torch.int32)      # rows repeat across classes, unique within one
+    filt = torch.tensor([0, 0, 1, 1, 1, 2, 2, 2], dtype=torch.int32)
+    gkv_a = torch.randn(rows, I2).to(T); ggath = torch.randn(idx.numel(), I2).to(T)
+    gouts = [torch.randn(n, 16) for _ in range(3)]
+
+    def run(native):
+        dev = DEV if native else "cpu"
+        dtp = T if native else torch.float64
+        zz = z.to(dev, dtp).requires_grad_()
+        Wkv = wkv.to(dev, torch.float32 if native else dtp).requires_grad_()
+        Wc = [w.to(dev, torch.float32 if native else dtp).requires_grad_() for w in wcs]
+        Bc = [b.to(dev, torch.float32 if native else dtp).requires_grad_() for b in bcs]
+        Em = [None if e is None else e.to(dev, torch.float32 if native else dtp).requires_grad_() for e in embs]
+        if native:
+            kv, c = ops.kv_ctx_projections(zz, r0, n, Wkv, Wc, Bc)
+            xs = ops.split_cols_f32(c, [16, 16, 16], Em)
+            kv2, gath = ops.fork_gather_rows(kv, idx.to(dev), filt=filt.to(dev), nfilt=3)
+        else:
+            kv = zz @ Wkv.t()
+            xs = []
+            for w, b, e in zip(Wc, Bc, Em):
+                x = zz[r0:] @ w.t() + b
+                xs.append(x if e is None else x + e.reshape(1, -1))
+            kv2 = kv
+            gath = torch.stack([kv[i] if i >= 0 else torch.zeros_like(kv[0]) for i in idx.tolist()])
+        loss = (kv2.double() * gkv_a.to(dev).double()).sum() + (gath.double() * ggath.to(dev).double()).sum()
+        for x, g in zip(xs, gouts):
+            loss = loss + (x.double() * g.to(dev).double()).sum()
+        loss.backward()
+        return kv, gath, xs, zz.grad, Wkv.grad, [w.grad for w in Wc], [b.grad for b in Bc], [None if e is None else e.grad for e in Em]
+
+    a, b = run(True), run(False)
+    tol = TOL[T]
+    close(a[0], b[0], tol, "kv"); close(a[1], b[1], tol, "gathered")
+    for i in range(3):
+        close(a[2][i], b[2][i], tol, "ctx %d" % i)
+        close(a[5][i], b[5][i], tol * GRAD, "d proj_context.weight %d" % i)
+        close(a[6][i], b[6][i], tol * GRAD, "d proj_context.bias %d" % i)
+        if embs[i] is not None:
+            close(a[7][i], b[7][i], tol * GRAD, "d task embedding %d" % i)
+    close(a[3], b[3], tol * GRAD, "dz"); close(a[4], b[4], tol * GRAD, "d to_kv.weight")
+
+
 @pytest.mark.parametrize("F", [2048, 85])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 def test_geglu_gelu(F, T):
