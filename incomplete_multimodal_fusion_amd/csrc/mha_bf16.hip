@@ -968,6 +968,7 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant >= 30 && g_variant <= 32) return mha_sh_fwd(d, g_variant - 20, st);   // two tiles per barrier (+ its diagnostics)
     if (head_dim == 64 && g_variant == 35) return mha_sh_fwd(d, 10, st);
+    if (head_dim == 64 && g_variant == 45) return mha_sh_fwd(d, 4, st);   // diagnostic: sixteen global waves (wrong modality rows)
     if (head_dim == 64 && (g_variant == 40 || g_variant == 41)) return mha_sh_fwd(d, g_variant - 20, st);   // four loader waves (+ stream only)
     if (head_dim == 64 && g_variant >= 5 && g_variant <= 8) return mha_sh_fwd(d, g_variant - 5, st);   // sample-head forward (mha_sh.hip); 6 / 7 / 8: diagnostics
     // default: the sample-head kernel wherever a sample has enough query rows to fill its 16 waves (encoder blocks); the
@@ -1004,7 +1005,7 @@ int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) 
 
 int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int g_variant, hipStream_t st) {
     if (max_q_tiles > MAXT || max_k_tiles > MAXT) return MMAE_ERR_ARG;
-    if ((g_variant >= 30 && g_variant <= 32) || g_variant == 40 || g_variant == 41) g_variant = 0;   // forward-only variants: default backward
+    if ((g_variant >= 30 && g_variant <= 32) || g_variant == 40 || g_variant == 41 || g_variant == 45) g_variant = 0;   // forward-only variants: default backward
     if (g_variant == 35) g_variant = 5;                      // two-tile forward + sample-head dQ
     d.max_tiles = max_q_tiles;
     // dQ: the tile-per-block kernel stays the default.  The query-stationary sample-head kernel (mha_sh.hip: mha_sh_dq_kernel) runs

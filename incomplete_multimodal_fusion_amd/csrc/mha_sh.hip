@@ -329,7 +329,8 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
     __shared__ __attribute__((aligned(1024))) bf16 ringV[SH_NS][4096];
     __shared__ __attribute__((aligned(1024))) bf16 qst[16][32 * 64];       // wave-private Q staging: 32 rows x 64
     const int tid = threadIdx.x, lane = tid & 63, wave = sh_uni(tid >> 6), r = lane & 31, hh = lane >> 5;
-    const bool local = wave >= 8;                                   // role of this wave
+    const bool local = MODE == 4 ? false : wave >= 8;               // role of this wave (MODE 4, diagnostic: sixteen global waves --
+                                                                    // waves 8-15 repeat the fusion queries of 0-7: what would twice the global work per step cost?)
     const int qw = wave & 7;                                        // its 32-query block inside a 256-query chunk
     const int hgroups = p.H / hpb;
     const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * hpb;
@@ -1140,6 +1141,7 @@ int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
     else if (mode == 10) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 1>), grid, blk, 0, st, d, hpb);     // two tiles per barrier
     else if (mode == 11) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 1>), grid, blk, 0, st, d, hpb);
     else if (mode == 12) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 1>), grid, blk, 0, st, d, hpb);
+    else if (mode == 4) MMAE_LAUNCH((mha_sh_fwd_kernel<4, 0>), grid, blk, 0, st, d, hpb);      // diagnostic: sixteen global waves
     else if (mode == 20) MMAE_LAUNCH((mha_sh_fwd_kernel<0, 2>), grid, blk, 0, st, d, hpb);     // four loader waves
     else if (mode == 21) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 2>), grid, blk, 0, st, d, hpb);
     else MMAE_LAUNCH((mha_sh_fwd_kernel<0, 0>), grid, blk, 0, st, d, hpb);
