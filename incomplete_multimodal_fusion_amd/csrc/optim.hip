@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const bf16* __restrict_
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= n) return;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < S; ++s) {
         union { uint4 q; bf16 e[8]; } v;
         v.q = *reinterpret_cast<const uint4*>(part + (long)s * n + i);

@@ -243,18 +243,20 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
     const int col = blockIdx.x * 64 + c;
     const int qn = blockIdx.y;
     float* out = qn == 0 ? o0 : qn == 1 ? o1 : qn == 2 ? o2 : o3;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (col < D && out) {
         const float* base = ws + (long)qn * D + col;
         const long stride = 4L * D;
         int b = rg;
-        for (; b + 48 < nblk; b += 64) {
+        for (; b + 112 < nblk; b += 128) {                    // eight independent loads in flight (L2 hits: latency, not bytes)
             s0 += base[(long)b * stride]; s1 += base[(long)(b + 16) * stride];
             s2 += base[(long)(b + 32) * stride]; s3 += base[(long)(b + 48) * stride];
+            s4 += base[(long)(b + 64) * stride]; s5 += base[(long)(b + 80) * stride];
+            s6 += base[(long)(b + 96) * stride]; s7 += base[(long)(b + 112) * stride];
         }
         for (; b < nblk; b += 16) s0 += base[(long)b * stride];
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    red[threadIdx.x] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (rg == 0 && col < D && out) {
         float s = 0.f;
@@ -1366,17 +1368,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ ws, int nblk, int cols, float* __restrict__ out) {
     __shared__ float red[1024];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (c < cols) {
         const float* base = ws + c;
         int b = rg;
-        for (; b + 48 < nblk; b += 64) {
+        for (; b + 112 < nblk; b += 128) {
             s0 += base[(long)b * cols]; s1 += base[(long)(b + 16) * cols];
             s2 += base[(long)(b + 32) * cols]; s3 += base[(long)(b + 48) * cols];
+            s4 += base[(long)(b + 64) * cols]; s5 += base[(long)(b + 80) * cols];
+            s6 += base[(long)(b + 96) * cols]; s7 += base[(long)(b + 112) * cols];
         }
         for (; b < nblk; b += 16) s0 += base[(long)b * cols];
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    red[threadIdx.x] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (rg == 0 && c < cols) {
         float s = 0.f;

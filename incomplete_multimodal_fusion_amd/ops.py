@@ -333,24 +333,27 @@ class _KvCtx(torch.autograd.Function):
                 gz = torch.nn.functional.linear(gkv, wt if wt is not None else wkv_c.t().contiguous())
                 zs = gz[r0:r0 + n]
                 torch.addmm(zs, gc, wc, out=zs)
-            gwkv = _wgrad(gkv, z, gvkv)
-            gwc = _wgrad(gc, z[r0:r0 + n], None)
-            gb = colsum(gc) if bdt else None
+            need_kv = ctx.needs_input_grad[3]                      # a frozen weight gets no gradient (and no flat-buffer write)
+            need_w = [ctx.needs_input_grad[5 + i] for i in range(nw)]
+            need_b = [ctx.needs_input_grad[5 + nw + i] for i in range(len(bdt))]
+            gwkv = _wgrad(gkv, z, gvkv) if need_kv else None
+            gwc = _wgrad(gc, z[r0:r0 + n], None) if any(need_w) else None
+            gb = colsum(gc) if (bdt and any(need_b)) else None
         gws, gbs, off = [], [], 0
-        for sz, dt_ in zip(sizes, wdt):
-            g = gwc[off:off + sz]
-            gws.append(g if g.dtype == dt_ else g.to(dt_))
+        for i, (sz, dt_) in enumerate(zip(sizes, wdt)):
+            g = gwc[off:off + sz] if need_w[i] else None
+            gws.append(g if (g is None or g.dtype == dt_) else g.to(dt_))
             off += sz
         off = 0
-        for sz, dt_ in zip(sizes, bdt):
-            g = gb[off:off + sz]
-            gbs.append(g if g.dtype == dt_ else g.to(dt_))
+        for i, (sz, dt_) in enumerate(zip(sizes, bdt)):
+            g = gb[off:off + sz] if need_b[i] else None
+            gbs.append(g if (g is None or g.dtype == dt_) else g.to(dt_))
             off += sz
-        if gvkv is not None:
+        if need_kv and gvkv is not None:
             from .engine import grads_written_in_place
             grads_written_in_place((ctx.wkv,))
             gwkv = None
-        elif gwkv.dtype != dkv_:
+        elif gwkv is not None and gwkv.dtype != dkv_:
             gwkv = gwkv.to(dkv_)
         return (gz, None, None, gwkv, None, *gws, *gbs)
 
