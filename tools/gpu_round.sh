@@ -25,7 +25,7 @@ for s in $steps; do
     attnx) for sp in ${ATTN_SPLITS:-384 64,64,64}; do timeout -k 10 300 python tools/bench_attn.py --variants ${ATTN_VARIANTS:-0} --split $sp --rounds 3 > $OUT/attnx_$sp.log 2>&1; guard $? attnx; echo "split $sp"; grep "^variant" $OUT/attnx_$sp.log; done ;;
     attnsq) rm -rf $OUT/attnsq; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/attnsq -- python3 tools/bench_attn.py --variants ${ATTN_VARIANTS:-0} --rounds 1 --iters 3 > $OUT/attnsq.log 2>&1; guard $? attnsq ;;
     profiles) du -sh $OUT/stats $OUT/sq $OUT/fetch $OUT/write 2>/dev/null; bash tools/make_profiles.sh ${PROFILE_TAG:-r02} 5 $OUT/profiles; guard $? profiles; rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write ;;
-    pick) timeout -k 10 1000 python -m pytest $PYTEST_ARGS -q --timeout 600 > $OUT/pick.log 2>&1; guard $? pick; tail -25 $OUT/pick.log ;;
+    pick) eval "timeout -k 10 1000 python -m pytest $PYTEST_ARGS -q --timeout 600" > $OUT/pick.log 2>&1; guard $? pick; tail -25 $OUT/pick.log ;;   # eval: PYTEST_ARGS may carry a quoted -k expression
     smoke) timeout -k 10 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; guard $? smoke; tail -2 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
