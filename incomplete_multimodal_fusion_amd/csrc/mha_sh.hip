@@ -33,6 +33,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define LDS_AS __attribute__((address_space(3)))
 
+#ifndef SH_SKEW
+#define SH_SKEW 0
+#endif
+#ifndef SH_SLEEP_CLASS
+#define SH_SLEEP_CLASS (-1)
+#endif
 #define SH_NS 4                 // ring stages
 #define SH_D 3                  // tiles in flight ahead of the consumer
 #define SH_MAXT 64              // key tiles per sample (one lane each)
@@ -503,6 +509,10 @@ __global__ __launch_bounds__(1024) void mha_sh_fwd_kernel(MhaDesc p, int hpb) {
             SH_T(1);
             if (VAR != 1) { if (lj < G) issue_ring(); }
             else if (g >= 2) { if (lj < G) issue_ring(); if (lj < G) issue_ring(); }   // into the stages of the pair just finished
+            if (VAR == 1 && SH_SKEW > 0 && wave >= 4 && wave < 8) __builtin_amdgcn_s_sleep(SH_SKEW);   // experiment: phase offset
+                                                                    // between the two global waves of a SIMD (units of 64 cycles)
+            if (SH_SLEEP_CLASS >= 0 && (wave >> 2) == SH_SLEEP_CLASS) __builtin_amdgcn_s_sleep(8);   // slack probe: 512 idle cycles per
+                                                                    // step in ONE wave class (0: waves 0-3 ... 3: 12-15, the loaders)
         }
         const int tinf = t_info(t), kn = tinf & 255, sg = (tinf >> 8) & 255, fl = tinf >> 16;
         const int h = h0 + hi;
