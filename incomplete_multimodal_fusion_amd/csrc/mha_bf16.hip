@@ -499,6 +499,143 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_kernel(MhaDesc p) {
 }
 
 
+// Head-looping form of the dQ kernel (variant 23): one block per (sample, 64-query tile) walks the H heads.  The segment table,
+// the tile choice and the key-tile list are the same for every head of a sample, so they are built once; the next head's Q / dO /
+// O rows, its lse and its first K/V tile are requested while the current head's last key tile is being processed -- the two
+// dependent trips to memory that open every block of the tile-per-(head) kernel (43 % of a block's life at S = 640) are paid once
+// per 8 heads and otherwise hidden.
+template <int DH>
+__global__ __launch_bounds__(256, 2) void mha_bf16_bwd_dq_heads_kernel(MhaDesc p) {
+    typedef Geo<DH> G;
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * G::KP];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * G::KP];
+    __shared__ int tl_row[MAXT], tl_n[MAXT], tl_cnt;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const BlockSel bs = decode_block(blockIdx.x, p.max_tiles, p.B, 1);          // (sample, tile): the head is the loop below
+    if (bs.b < 0) return;
+    const int b = bs.b;
+    SegTab st; st.load(p, b, lane);
+    const TileSel ts = pick_tile<64>([&](int s) { return st.ql(s); }, p.nseg, bs.t);
+    if (ts.seg < 0) return;
+    const long qrow0 = (long)st.qs(ts.seg) + ts.t0;
+    const KeyPlan kp = key_plan(ts.seg, p.nseg, st.kl(ts.seg), p.empty_mode);
+    if (wave == 0) {
+        int n = 0;
+        if (!kp.uniform)
+            for (int s = kp.begin; s < kp.end; ++s) {
+                const int L = st.kl(s), r0 = st.ks(s);
+                for (int j0 = 0; j0 < L && n < MAXT; j0 += 64) { if (lane == 0) { tl_row[n] = r0 + j0; tl_n[n] = min(64, L - j0); } ++n; }
+            }
+        if (lane == 0) tl_cnt = n;
+    }
+    const int myq = wave * 16 + lr;
+    const bool qvalid = myq < ts.n;
+    const long qr = qrow0 + myq;
+    const bf16* qbase = reinterpret_cast<const bf16*>(p.q) + qr * p.q_stride + 8 * g;
+    const bf16* dobase = reinterpret_cast<const bf16*>(p.dout) + qr * p.do_stride + 8 * g;
+    const bf16* obase = reinterpret_cast<const bf16*>(p.o) + qr * p.o_stride + 8 * g;
+    // prefetch registers: the rows of the NEXT head
+    bf16x8 qn[G::KS], don[G::KS], on[G::KS];
+    float lsen = 0.f;
+    auto load_rows = [&](int h) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            qn[ks] = qvalid ? ld8(qbase + h * DH + 32 * ks) : z8();
+            don[ks] = qvalid ? ld8(dobase + h * DH + 32 * ks) : z8();
+            on[ks] = qvalid ? ld8(obase + h * DH + 32 * ks) : z8();
+        }
+        lsen = qvalid ? p.lse[(long)h * p.stat_stride + qr] : 0.f;
+    };
+    load_rows(0);
+    __syncthreads();
+    const int ntile = uni(tl_cnt);
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    StageIdx<DH, NT> ixk, ixv;
+    ixk.init(tid, p.k_stride, 0);
+    ixv.init(tid, p.v_stride, 0);
+    const bf16* kfrag = Ks + lr * G::KP + 8 * g;
+    const bf16* vfrag = Vs + lr * G::KP + 8 * g;
+    bf16x8 kreg[G::NCH], vreg[G::NCH];
+    if (ntile > 0) {
+        const long r0 = uni(tl_row[0]); const int n0 = uni(tl_n[0]);
+        tile_load2<DH, NT>(kg + r0 * p.k_stride, ixk, n0, kreg);
+        tile_load2<DH, NT>(vg + r0 * p.v_stride, ixv, n0, vreg);
+    }
+    const float c = p.scale * LOG2E;
+    const long plane = (long)p.H * p.stat_stride;
+    for (int h = 0; h < p.H; ++h) {
+        bf16x8 qf[G::KS], dof[G::KS];
+        float dpart = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            dof[ks] = don[ks];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dpart += (float)don[ks][j] * (float)on[ks][j];
+                qf[ks][j] = (bf16)((float)qn[ks][j] * c);
+            }
+        }
+        const float delta = rows_sum(dpart);
+        const float lse2 = lsen * LOG2E;
+        if (qvalid && g == 0) {
+            const long at = (long)h * p.stat_stride + qr;
+            p.delta[at] = delta; p.delta[at + plane] = -lse2; p.delta[at + 2 * plane] = -delta;
+        }
+        const f32x4 neg_lse4 = f32x4{-lse2, -lse2, -lse2, -lse2}, neg_delta4 = f32x4{-delta, -delta, -delta, -delta};
+        f32x4 dqacc[G::DT];
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ntile == 0 && h + 1 < p.H) load_rows(h + 1);
+        for (int t = 0; t < ntile; ++t) {
+            __syncthreads();
+            tile_store2<DH, NT>(Ks, ixk, kreg);
+            tile_store2<DH, NT>(Vs, ixv, vreg);
+            __syncthreads();
+            if (t + 1 < ntile) {
+                const long r1 = uni(tl_row[t + 1]); const int n1 = uni(tl_n[t + 1]);
+                tile_load2<DH, NT>(kg + r1 * p.k_stride + h * DH, ixk, n1, kreg);
+                tile_load2<DH, NT>(vg + r1 * p.v_stride + h * DH, ixv, n1, vreg);
+            } else if (h + 1 < p.H) {                       // last key tile of this head: the next head's rows and first tile
+                const long r1 = uni(tl_row[0]); const int n1 = uni(tl_n[0]);
+                tile_load2<DH, NT>(kg + r1 * p.k_stride + (h + 1) * DH, ixk, n1, kreg);
+                tile_load2<DH, NT>(vg + r1 * p.v_stride + (h + 1) * DH, ixv, n1, vreg);
+                load_rows(h + 1);
+            }
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                s[t4] = neg_lse4; dp[t4] = neg_delta4;
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const bf16x8 kfr = ld8(kfrag + 16 * t4 * G::KP + 32 * ks);
+                    const bf16x8 vfr = ld8(vfrag + 16 * t4 * G::KP + 32 * ks);
+                    s[t4] = mma16(kfr, qf[ks], s[t4]);
+                    dp[t4] = mma16(vfr, dof[ks], dp[t4]);
+                }
+            }
+            bf16x8 dsb[2];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t4][r] = fast_exp2(s[t4][r]) * dp[t4][r];
+            dsb[0] = pack8(s[0], s[1]);
+            dsb[1] = pack8(s[2], s[3]);
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt) dqacc[dt] = mma16(tr_frag(Ks, G::KP, 32 * ks2, 16 * dt, lane), dsb[ks2], dqacc[dt]);
+        }
+        if (qvalid) {
+            bf16* dqp = reinterpret_cast<bf16*>(p.dq) + qr * p.dq_stride + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) st4(dqp + 16 * dt, dqacc[dt] * p.scale);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ backward: dK, dV
 // No per-element masks either: a padded query row has Q = dO = 0 (zero-filled image) and lse = delta = 0, so P is finite
 // and both dO^T P and Q^T dS get exactly 0 from it; a padded key column only pollutes its own (never stored) column.
@@ -965,6 +1102,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 // ------------------------------------------------------------------------------------------------------ host side
 // `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
+    if (g_variant == 23) g_variant = 0;                      // backward-only variant (head-looping dQ): default forward
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant >= 30 && g_variant <= 32) return mha_sh_fwd(d, g_variant - 20, st);   // two tiles per barrier (+ its diagnostics)
     if (head_dim == 64 && g_variant == 35) return mha_sh_fwd(d, 10, st);
@@ -1017,6 +1155,9 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
         const int rc = mha_sh_dq(d, (g_variant == 6 || g_variant == 7) ? g_variant - 5 : 0, st);
         if (rc != MMAE_OK) return rc;
     } else
+    if (head_dim == 64 && g_variant == 23) {                 // head-looping blocks: (sample, tile) grid, prefetch across heads
+        MMAE_LAUNCH((mha_bf16_bwd_dq_heads_kernel<64>), dim3(xcd_grid(d.B, 1, max_q_tiles)), dim3(256), 0, st, d);
+    } else
     if (head_dim == 64 && g_variant == 22) {                 // 128-query tiles: measured +-1 % (207 VGPRs, 2 waves/SIMD) -> not default
         d.max_tiles = (max_q_tiles + 1) / 2 + d.nseg;
         MMAE_LAUNCH((mha_bf16_bwd_dq_kernel<64, 2>), dim3(xcd_grid(d.B, d.H, d.max_tiles)), dim3(256), 0, st, d);
@@ -1026,7 +1167,7 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
     d.max_tiles = max_k_tiles;
     // dK / dV: the key-stationary sample-head kernel (mha_sh.hip) where a sample has enough keys to fill it (encoder blocks) or
     // when asked for (variant 5: tests); variant 3 = the tile-per-block kernels of round 2 throughout
-    if (head_dim == 64 && mha_sh_dkdv_supported(d) && (g_variant == 5 || (g_variant == 0 && d.max_k_rows >= 128))) return mha_sh_dkdv(d, 0, st);
+    if (head_dim == 64 && mha_sh_dkdv_supported(d) && (g_variant == 5 || ((g_variant == 0 || g_variant == 23) && d.max_k_rows >= 128))) return mha_sh_dkdv(d, 0, st);
     if (head_dim == 64 && mha_sh_dkdv_supported(d) && (g_variant == 6 || g_variant == 7)) return mha_sh_dkdv(d, g_variant - 5, st);   // diagnostics: stream only / no ring DMA
     if (head_dim == 64) MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<64>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);
     else MMAE_LAUNCH((mha_bf16_bwd_dkdv_kernel<32>), dim3(xcd_grid(d.B, d.H, max_k_tiles)), dim3(256), 0, st, d);

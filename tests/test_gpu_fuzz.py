@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4),
-                                       (torch.bfloat16, 5)])
+                                       (torch.bfloat16, 5), (torch.bfloat16, 23)])
 def test_fuzz_attention_segments(T, variant):
     from incomplete_multimodal_fusion_amd import ops
     rng = random.Random(1234)

@@ -287,7 +287,7 @@ def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
 # 16x16x32 forward of round 1; 4 = 32x32x16 with 256-query tiles)
 @pytest.mark.parametrize("T,dh,variant", [(torch.float32, 64, 0), (torch.float32, 32, 0), (torch.bfloat16, 64, 0),
                                           (torch.bfloat16, 32, 0), (torch.bfloat16, 64, 2), (torch.bfloat16, 64, 4),
-                                          (torch.bfloat16, 64, 5)])
+                                          (torch.bfloat16, 64, 5), (torch.bfloat16, 64, 23)])
 @pytest.mark.parametrize("empty_mode", [0, 1])
 def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     from incomplete_multimodal_fusion_amd import ops
@@ -328,7 +328,7 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
 
 
 @pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4),
-                                       (torch.bfloat16, 5)])
+                                       (torch.bfloat16, 5), (torch.bfloat16, 23)])
 @pytest.mark.parametrize("shift", [0.0, -40.0])
 def test_mha_online_softmax_rescale_branch(T, variant, shift):
     """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path; the 32x32x16 forward
