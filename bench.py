@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
-PROFILE_ROUNDS = ("r03", "r02", "r01")   # newest committed rocprofv3 summaries first
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")   # newest committed rocprofv3 summaries first
 
 
 # ---------------------------------------------------------------------------------------------------------- launcher
@@ -95,7 +95,7 @@ def cpu_model_name():
 def cpu_baseline(args):
     """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this box's host cores: same model,
     same step definition (fwd + losses + bwd + AdamW), fp32, a bounded sample of the workload (B = 8, >= 3
-    timed steps when the host manages them inside ~45 s)."""
+    timed steps when the host manages them inside ~60 s; SURVEY 8d asks for >= 5, the default)."""
     from oracle import mmae_oracle as O
     from incomplete_multimodal_fusion_amd.pretrain import get_model
     O.set_fused_primitives(True)     # LayerNorm / GELU via the fused functionals the reference calls: with them the port costs
@@ -130,7 +130,7 @@ def cpu_baseline(args):
         print("[cpu_baseline] step %d: %.2f s (%d threads)" % (it, dt_, cores), file=sys.stderr, flush=True)
         if it > 0 or dt_ > 20.0:                     # a slow host: keep the (warm-up) step as the sample and stop
             times.append(dt_)
-        if time.perf_counter() - t_begin > 45.0 and times:
+        if time.perf_counter() - t_begin > 60.0 and times:
             break
     t = sum(times) / len(times)
     return {"value": round(B / t, 4), "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
@@ -138,7 +138,7 @@ def cpu_baseline(args):
                       (args.model, args.input_size, args.input_size, B, N, len(times), t)}
 
 
-def step_flops(args):
+def step_flops(args, per_layer=False):
     """Algorithmic FLOPs of one optimizer step per sample, SURVEY.md 8(d): MACs_fwd of the reference-dense formulation
     (Block + Block_Fusion as written + pooling heads + patch embedding + decoders), FLOPs_step = 6 * MACs_fwd (forward 2x,
     backward 4x, no recompute credit); and the same with Block_Fusion as executed here (K/V of every row once, query /
@@ -161,6 +161,8 @@ def step_flops(args):
     embed = sum(P * (64 if k else c) * p * p * D for c, k in zip(C, classes))     # class map: 64-wide class embedding per pixel
     dec = sum(P * D * Dd + Ld * (4 * P * Dd * Dd + 2 * P * P * Dd + 8 * P * Dd * Dd) + P * Dd * c * p * p for c in C)
     rest = pool + ctr + embed + dec
+    if per_layer:                                   # one encoder layer (Block_Fusion + Block), forward + backward: bench's roofline_block
+        return 6.0 * (block + fus_dense) / L, 6.0 * (block + fus_exec) / L
     return 6.0 * (block + fus_dense + rest), 6.0 * (block + fus_exec + rest)
 
 
@@ -175,6 +177,20 @@ def workload_string(args, mask_desc):
             % (args.model, D, L, h, len(doms), "+".join("%s:%dch" % (d, c) for d, c in zip(doms, C)), args.input_size,
                args.input_size, args.num_encoded_tokens, len(doms) * (args.input_size // 16) ** 2, mask_desc,
                "fusion blocks" if args.fusion_blocks else "no fusion blocks (multimae_quadruplet)", losses))
+
+
+def replayed_from(stem, this_ms):
+    """Provenance of a counter figure that cannot be collected in-process and is therefore REPLAYED from a committed rocprofv3
+    summary of this command: the file, the commit whose tree the profiled run measured (stamped by tools/stamp_profiles.py when the
+    summary was copied into profiles/), the kernel time per step of the profiled run -- and whether it still describes THIS run:
+    `valid` is False when the two step times differ by more than 5 % (the replayed fields are then printed as null)."""
+    js, rnd = _profile_json(stem)
+    if js is None:
+        return None, False
+    prof_ms = (js.get("step") or {}).get("kernel_ms_per_step") or js.get("kernel_ms_per_step")
+    ok = bool(prof_ms) and abs(prof_ms - this_ms) <= 0.05 * this_ms
+    return {"file": "profiles/%s_%s.json" % (rnd, stem), "git": js.get("git"), "profiled_ms_per_step": prof_ms,
+            "this_run_ms_per_step": round(this_ms, 2), "valid": ok}, ok
 
 
 def gemm_roofline():
@@ -403,7 +419,7 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=5)
     ap.add_argument("--bucket-mb", type=int, default=128)
     ap.add_argument("--engine", type=int, default=1, help="1: flat-buffer fused AdamW + bf16 shadow weights (csrc/optim.hip); "
                     "0: torch.optim.AdamW(fused=True) on the fp32 parameters")
@@ -420,6 +436,10 @@ def main():
     ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3; "
                     "'auto' = both at N = 1 with default main settings, none otherwise; 'none'")
     ap.add_argument("--clip-grad", dest="clip_grad", type=float, default=0.0, help="> 0: device-side global-norm clipping")
+    ap.add_argument("--block-timer", dest="block_timer", type=int, default=1, help="1: HIP-event brackets around encoder layer 6 "
+                    "(four events per step) for roofline_block")
+    ap.add_argument("--tuning-env", dest="tuning_env", action="store_true", help="A/B runs (tools/ab_bench.sh): map MMAE_* tuning "
+                    "variables onto the implementation switches (tools/tuning_env.py); the default run reads none")
     ap.add_argument("--dry-run", dest="dry_run", action="store_true", help="launcher rehearsal on CPU/gloo (see dry_main)")
     ap.add_argument("--tune-out", default="", help="write the TunableOp table here on exit (to refresh the committed table)")
     args = ap.parse_args()
@@ -437,6 +457,9 @@ def main():
     import torch.distributed as dist
     from incomplete_multimodal_fusion_amd import dp, ops
     from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    if args.tuning_env:
+        from tools import tuning_env
+        tuning_env.apply()
     distributed = dp.init_distributed()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
@@ -503,8 +526,12 @@ def main():
     for _ in range(args.warmup):
         losses = step(x)
     ops.set_kernel_timer([prof, prof_ln])
+    # roofline_block: HIP events around ONE encoder layer (Block_Fusion + Block) of the middle of the stack, forward and backward
+    block_layer = min(6, model.depth - 1)
+    model.layer_timer = ops.LayerTimer(block_layer) if (model.depth > 1 and args.block_timer) else None
     dt, losses, per_step_ms, ranks_dt = timed_region(step, x, args.steps, distributed, device)
     ops.set_kernel_timer(None)
+    layer_timer, model.layer_timer = model.layer_timer, None
     loss_val = float(losses["loss"])
     assert loss_val == loss_val, "non-finite loss"
 
@@ -554,6 +581,11 @@ def main():
         ln_ms = max(ln_raw_ms - ev_ms, 1e-6)
         ln_gbs = ln_bytes / ln_n / (ln_ms * 1e-3) / 1e9 if ln_n else 0.0
         mask_desc = ("per-sample" if args.per_sample else "batch-shared") + (" + modality dropout" if args.dropout else "")
+        # counter figures are REPLAYED from the committed rocprofv3 summaries of this very command (they cannot be collected
+        # in-process): only for the profiled configuration, and only while the profiled step time is within 5 % of this run's
+        replay_ok = not args.fp32 and args.batch == 256 and default_doms and not (args.per_sample or args.dropout or args.staging)
+        rep_sq, sq_ok = replayed_from("sq_step", ms) if replay_ok else (None, False)
+        rep_hbm, hbm_ok = replayed_from("pmc_hbm", ms) if replay_ok else (None, False)
         out = {
             "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -569,7 +601,7 @@ def main():
             "roofline": {"kernel": "add_ln_bwd_fast_kernel<bf16,bf16,3,double,up,gx,gdelta>" if not args.fp32 else "add_ln_bwd_fast_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (not args.fp32 and args.batch == 256 and default_doms) else None,
+                         "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (replay_ok and hbm_ok) else None,
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n},
@@ -577,7 +609,7 @@ def main():
             "roofline_attention": {"kernel": "mha_sh_fwd_kernel<0>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
-                         "traffic": pmc_traffic("mha_sh_fwd") if (not args.fp32 and args.batch == 256 and default_doms) else None,
+                         "traffic": pmc_traffic("mha_sh_fwd") if (replay_ok and hbm_ok) else None,
                          "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
                          "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 64 * {"tiny": 3}.get(args.model, 8) * 2,
                          "avg_launch_ms": round(avg_ms, 4), "avg_bracket_ms": round(raw_ms, 4),
@@ -594,14 +626,31 @@ def main():
                                 "flops_per_sample_reference_dense": round(dense),
                                 "achieved_reference_dense": round(value * dense / 1e12, 1),
                                 "frac_reference_dense": round(value * dense / 1e12 / peak, 4)}
-        rg = gemm_roofline()
-        if rg is not None and not args.fp32 and args.batch == 256 and default_doms:
-            out["roofline_gemm"] = rg
+        if layer_timer is not None:
+            fw_ms, bw_ms, nst = layer_timer.summary()
+            ldense, lexec = step_flops(args, per_layer=True)
+            tot_ms = fw_ms + bw_ms
+            ach_b = args.batch * lexec / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            # the quantity north_star sets its >= 50 % MFMA target on: one fusion-attention block (Block_Fusion + Zorro-masked
+            # Block of one encoder layer), forward + backward incl. its weight gradients, measured live by HIP events on the
+            # stream it runs on; FLOPs = SURVEY 8(d)'s per-layer terms x 6 (executed: fusion-slot shortcut; reference-dense beside it)
+            out["roofline_block"] = {"what": "encoder layer %d: Block_Fusion + Block, forward + backward (HIP events, %d steps)" % (block_layer, nst),
+                                     "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TF,
+                                     "forward_ms": round(fw_ms, 3), "backward_ms": round(bw_ms, 3),
+                                     "flops_per_sample_executed": round(lexec), "flops_per_sample_reference_dense": round(ldense),
+                                     "achieved": round(ach_b, 1), "frac": round(ach_b / MFMA_BF16_PEAK_TF, 4),
+                                     "achieved_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12, 1) if tot_ms > 0 else 0.0,
+                                     "frac_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if tot_ms > 0 else 0.0}
+        if replay_ok:
+            # replayed (not measured in this process): null when the profiled step no longer matches this run
+            rg = gemm_roofline()
+            out["roofline_gemm"] = rg if (rg is not None and sq_ok) else None
+            mb = mfma_busy()
+            out["mfma_busy_pct"] = mb["pct"] if (mb is not None and sq_ok) else None
+            out["mfma_busy_source"] = mb["source"] if mb is not None else None
+            out["replayed_from"] = {"sq_step": rep_sq, "pmc_hbm": rep_hbm,
+                                    "fields": "mfma_busy_pct, roofline_gemm <- sq_step; roofline.traffic, roofline_attention.traffic <- pmc_hbm"}
         out.update(dpdiag)
-        mb = mfma_busy()
-        if mb is not None and not args.fp32 and args.batch == 256 and default_doms:
-            out["mfma_busy_pct"] = mb["pct"]
-            out["mfma_busy_source"] = mb["source"]
         out.update(leg_out)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args) if default_doms else None      # the CPU leg is the headline configuration's

@@ -61,7 +61,9 @@ def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: flo
         for i, st in bsd["state"].items():
             state[len(params) + int(i)] = st
     groups = [dict(common, lr_scale=g.get("lr_scale", 1.0), params=list(range(len(params)))),
-              dict(common, lr_scale=balancer_lr_scale, params=list(range(len(params), len(params) + nb)))]
+              # the reference stores lr * lr_scale in a group (optim_factory.py:136-150 scales the group's lr when it is set)
+              dict(common, lr=g["lr"] * balancer_lr_scale, lr_scale=balancer_lr_scale,
+                   params=list(range(len(params), len(params) + nb)))]
     return {"state": state, "param_groups": groups}
 
 

@@ -464,6 +464,7 @@ extern "C" int mmae_mha_fwd_variant(int dtype, int head_dim, int B, int H, int n
     d.q_start = q_seg_start; d.q_len = q_seg_len; d.k_start = k_seg_start; d.k_len = k_seg_len;
     d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_tiles = max_q_rows / 64 + nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows;
     d.scale = scale; d.empty_mode = empty_mode;
+    if (variant > 0) { d.hpb_req = (variant >> 8) & 15; variant &= 255; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_fwd<bf16, 64>(d, st) : launch_fwd<bf16, 32>(d, st)) : mha_bf16_fwd(d, head_dim, variant, st);
     return head_dim == 64 ? launch_fwd<float, 64>(d, st) : launch_fwd<float, 32>(d, st);
@@ -499,6 +500,7 @@ extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int n
     d.q_start = q_seg_start; d.q_len = q_seg_len; d.k_start = k_seg_start; d.k_len = k_seg_len;
     d.stat_stride = q_rows_total; d.B = B; d.H = H; d.nseg = nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows;
     d.scale = scale; d.empty_mode = empty_mode;
+    if (variant > 0) { d.hpb_req = (variant >> 8) & 15; variant &= 255; }
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, variant, st);

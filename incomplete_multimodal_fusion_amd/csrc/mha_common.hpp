@@ -18,6 +18,8 @@ struct MhaDesc {
     int max_q_rows, max_k_rows;   // upper bounds of a sample's query / key rows (all segments): kernel selection only
     float scale;
     int empty_mode;
+    int hpb_req;             // sample-head kernels: heads one workgroup walks; 0 = chosen from (B, H) (tests force 1 / 2 / H through
+                             // bits 8..11 of the `variant` argument of mmae_internal.h)
 };
 
 struct TileSel { int seg, t0, n; };

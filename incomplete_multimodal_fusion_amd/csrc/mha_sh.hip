@@ -1121,8 +1121,9 @@ __global__ __launch_bounds__(SQ_W * 64) void mha_sh_dq_kernel(MhaDesc p, int hpb
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
-static int sh_heads_per_block(int B, int H) {
+static int sh_heads_per_block(int B, int H, int req) {
     // one workgroup per CU when the batch allows it: a block walks `hpb` heads of its sample (hpb divides H)
+    if (req > 0 && req <= H && H % req == 0) return req;      // per-call override (MhaDesc::hpb_req: parity tests of the head walk)
     int hpb = H;
     while (hpb > 1 && (long)B * (H / hpb) < 256) {
         int d = hpb - 1;
@@ -1139,7 +1140,7 @@ bool mha_sh_applicable(const MhaDesc& d) {
 
 int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st) {
     if (d.max_k_rows / 64 + d.nseg > SH_MAXT || d.k_stride != d.v_stride || d.nseg > MAXSEG) return MMAE_ERR_ARG;
-    const int hpb = sh_heads_per_block(d.B, d.H);
+    const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
     const dim3 grid(d.B * (d.H / hpb)), blk(1024);
     if (mode == 1) MMAE_LAUNCH((mha_sh_fwd_kernel<1, 0>), grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH((mha_sh_fwd_kernel<2, 0>), grid, blk, 0, st, d, hpb);
@@ -1168,7 +1169,7 @@ bool mha_sh_dkdv_supported(const MhaDesc& d) {
 
 int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st) {
     if (!mha_sh_dkdv_supported(d)) return MMAE_ERR_ARG;
-    const int hpb = sh_heads_per_block(d.B, d.H);
+    const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
     const dim3 grid(d.B * (d.H / hpb)), blk(SD_W * 64);
     if (mode == 1) MMAE_LAUNCH(mha_sh_dkdv_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_dkdv_kernel<2>, grid, blk, 0, st, d, hpb);
@@ -1184,7 +1185,7 @@ bool mha_sh_dq_supported(const MhaDesc& d) {
 
 int mha_sh_dq(const MhaDesc& d, int mode, hipStream_t st) {
     if (!mha_sh_dq_supported(d)) return MMAE_ERR_ARG;
-    const int hpb = sh_heads_per_block(d.B, d.H);
+    const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
     const dim3 grid(d.B * (d.H / hpb)), blk(SQ_W * 64);
     if (mode == 1) MMAE_LAUNCH(mha_sh_dq_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_dq_kernel<2>, grid, blk, 0, st, d, hpb);

@@ -5,7 +5,10 @@
  *
  * variant  0  what mmae_mha_fwd / mmae_mha_bwd run
  *         -1  bf16 through the generic dtype-templated kernels of mha.hip instead of the bf16 fast path
- *        > 0  alternative tilings of the bf16 fast path (see mha_bf16.hip: mha_bf16_fwd / mha_bf16_bwd) */
+ *        > 0  bits 0..7: alternative tilings of the bf16 fast path (see mha_bf16.hip: mha_bf16_fwd / mha_bf16_bwd; 0 = product);
+ *             bits 8..11: heads ONE workgroup of the sample-head kernels (mha_sh.hip) walks, a divisor of H -- the product path
+ *             picks it from (B, H) (all H heads once B >= 256); tests force 1 / 2 / H at small B to reach the head loop, the
+ *             cross-head K/V prefetch and the ring accounting of the bench configuration.  0 = product choice. */
 #ifndef MMAE_INTERNAL_H
 #define MMAE_INTERNAL_H
 #ifdef __cplusplus

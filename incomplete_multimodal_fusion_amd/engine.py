@@ -213,6 +213,12 @@ class FlatAdamW:
                     self._pstep[id(p)] += 1
         self._refresh_transposed()
 
+    def skip_flag(self) -> Optional[torch.Tensor]:
+        """Device bool scalar: did the device-side control skip the most recent step()?  None when that step was not a controlled
+        one (nothing can have skipped it).  No host sync -- for companions that must follow the decision (PretrainStep's loss
+        balancer optimizer: the reference holds model and balancer in ONE optimizer, a skipped step skips both)."""
+        return (self._ctl[1] != 0.0) if self._ctl_used else None
+
     def last_step_skipped(self) -> bool:
         """Host sync: did the device-side control skip the most recent controlled step()?"""
         return bool(self._ctl[1].item() != 0.0)

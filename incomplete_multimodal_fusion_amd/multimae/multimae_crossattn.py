@@ -16,7 +16,6 @@ Exact algebraic shortcuts relative to the reference (rows are independent, resul
   * the (B,P,M+1,D) `all_tokens` tensor (:454-462) and the (B,h,S,S) score tensor are never materialised.
 """
 import itertools
-import os
 import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple, Union
@@ -34,8 +33,11 @@ from .zorro_utils import (Attention, Block, Block_Fusion, LayerNorm, Mlp, TokenT
 __all__ = ['pretrain_multimae_tiny', 'pretrain_multimae_base', 'pretrain_multimae_large', 'MultiMAE']
 
 
-FUSED_FINAL_CAST = os.environ.get('MMAE_FUSED_CAST', '1') != '0'    # A/B knob: bf16 copy of the final norm's output from the same pass
-FUSED_DECODER_CTX = os.environ.get('MMAE_FUSED_CTX', '1') != '0'   # A/B knob: one GEMM for every decoder's proj_context
+# Implementation switches (module attributes, no environment reads here: tools/tuning_env.py maps MMAE_* variables onto them for A/B runs)
+FUSED_FINAL_CAST = True     # bf16 copy of the final norm's output from the same pass
+FUSED_DECODER_CTX = True    # one GEMM for every decoder's proj_context
+DUAL_LAYERNORM = True       # one pass for the modality rows' two LayerNorm pairs
+DECODER_STREAMS = False     # the per-modality decoders on separate HIP streams (measured: no gain)
 
 class PredTokens:
     """Decoder output kept token-major, (B*P, C*p*p) in (c ph pw) order, so that the masked loss can be fused with the
@@ -105,7 +107,7 @@ class MultiMAE(nn.Module):
         self.attn_pool = Attention(dim=dim_tokens, dim_head=dim_head, heads=heads)
         self.fusion_tokens = nn.Parameter(trunc_normal_(torch.zeros(1, num_fusion_tokens, dim_tokens), std=0.02))
         self.has_fusion_blocks, self.has_contrastive_tokens = bool(fusion_blocks), bool(contrastive_tokens)
-        self.dual_layernorm = os.environ.get("MMAE_DUAL_LN", "1") != "0"   # one pass for the modality rows' two LayerNorm pairs
+        self.dual_layernorm = DUAL_LAYERNORM
         if contrastive_tokens:
             for d in self.domains:                                            # return_token_s1 / _s2 / _dem (:105-109)
                 setattr(self, 'return_token_' + d, nn.Parameter(torch.randn(1, 1, dim_tokens)))
@@ -124,10 +126,11 @@ class MultiMAE(nn.Module):
         self.per_sample_masks = False      # True: every sample draws / uses its own mask row (packed superset)
         self.fuse_unpatchify_loss = False  # True: preds are PredTokens (fused unpatchify + masked loss)
         self.check_masks = True            # explicit task_masks: verify kept count == num_encoded_tokens (host sync)
-        self.decoder_streams = os.environ.get("MMAE_DECODER_STREAMS", "0") == "1"   # True: the per-modality decoders run on separate HIP streams
+        self.decoder_streams = DECODER_STREAMS
         self._dec_streams = []
         self.side_stream_wgrad = False     # True: encoder weight-gradient GEMMs overlap the backward chain on a side
                                            # stream; the trainer must ops.join_wgrad_stream() before reading .grad
+        self.layer_timer = None            # an ops.LayerTimer: HIP-event brackets around that encoder layer (bench.py roofline_block)
 
         self._reset_parameters()
 
@@ -274,8 +277,13 @@ class MultiMAE(nn.Module):
             return a, a_off, b_off
 
         sw = self.side_stream_wgrad
+        lt = self.layer_timer
         for l in range(self.depth):
             blk = self.blocks[l]
+            timed = lt is not None and l == lt.layer and dm is df and dm is not None
+            if timed:
+                xm, xf, dm = ops.layer_mark(lt, 0, xm, xf, dm)
+                df = dm
             if self.has_fusion_blocks:
                 fus = self.fus_blocks[l]
                 # ---- Block_Fusion (DSI-MM zorro_utils.py:252-258 on multimae_crossattn.py:454-468) -----------------------
@@ -314,6 +322,8 @@ class MultiMAE(nn.Module):
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
                                            out_dtype=T)
             f = ops.feedforward_geglu(y, blk.mlp[1].weight, blk.mlp[3].weight)                    # (BN+BP, D)
+            if timed:
+                xm, xf, f = ops.layer_mark(lt, 1, xm, xf, f)
             dm, dm_off, df, df_off = f, 0, f, BN
             if l in taps:
                 tap_out.append((xf + f[BN:BN + BP].float()).reshape(B, P, D))

@@ -4,7 +4,6 @@ Every Function here launches hand-written gfx950 kernels through ctypes on torch
 projections between them are plain torch matmuls (hipBLASLt) chosen by the callers in multimae/.
 """
 import ctypes
-import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -60,6 +59,50 @@ def set_kernel_timer(t):
     _TIMERS = {x.name: x for x in ts if x.name != "mmae_mha_fwd"}
 
 
+class LayerTimer:
+    """HIP-event brackets around ONE encoder layer (Block_Fusion + Block), forward and backward, on the stream the layer runs on
+    (bench.py's roofline_block: the quantity north_star sets its MFMA target on).  The model calls layer_mark() at the layer's two
+    boundaries while `model.layer_timer` is set; every boundary is an identity autograd node over the whole layer-crossing state
+    (both residual parts + the pending delta), so its backward runs exactly when the layer's backward begins / has ended."""
+
+    def __init__(self, layer: int):
+        self.layer, self.ev = int(layer), {"f0": [], "f1": [], "b1": [], "b0": []}
+
+    def mark(self, key):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev[key].append(e)
+
+    def summary(self):
+        """-> (mean forward ms, mean backward ms, steps)"""
+        torch.cuda.synchronize()
+        n = min(len(v) for v in self.ev.values())
+        if n == 0:
+            return 0.0, 0.0, 0
+        fw = sum(a.elapsed_time(b) for a, b in zip(self.ev["f0"][:n], self.ev["f1"][:n])) / n
+        bw = sum(a.elapsed_time(b) for a, b in zip(self.ev["b1"][:n], self.ev["b0"][:n])) / n
+        return fw, bw, n
+
+
+class _LayerMark(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, timer, which, *ts):
+        ctx.timer, ctx.which = timer, which
+        ctx.set_materialize_grads(False)
+        timer.mark("f%d" % which)
+        return tuple(t.view_as(t) for t in ts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ctx.timer.mark("b%d" % ctx.which)
+        return (None, None, *gs)
+
+
+def layer_mark(timer, which, *ts):
+    """which 0: the layer's entry, 1: its exit.  Returns the tensors (as views) to be used in place of `ts`."""
+    return _LayerMark.apply(timer, which, *ts)
+
+
 # ------------------------------------------------------------------------------------------------ segments
 class Segments:
     """Device-side segment descriptors for the masked attention: int32 (B, nseg) start rows and lengths."""
@@ -108,10 +151,10 @@ def _split_k(rows: int, n_out: int, n_in: int) -> int:
     return s
 
 
-_SPLITK_CAP = int(os.environ.get("MMAE_SPLITK_CAP", "256"))     # workgroups the split aims at (256 CUs)
-_SPLITK_MAX = int(os.environ.get("MMAE_SPLITK_MAX", "32"))
+_SPLITK_CAP = 256     # workgroups the split aims at (256 CUs); tools/tuning_env.py overrides these module attributes for A/B runs
+_SPLITK_MAX = 32
 _WGRAD_STREAMS = {}
-WGRAD_STREAM_PRIORITY = int(os.environ.get('MMAE_WGRAD_PRIO', '-1'))   # high priority: own HW queue
+WGRAD_STREAM_PRIORITY = -1   # high priority: own HW queue
 WGRAD_SIDE_STREAM = True     # weight-gradient GEMMs of single-use weights run on a side HIP stream (see _Linear.backward)
 
 
@@ -482,23 +525,31 @@ class _MHA(torch.autograd.Function):
         return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None, None
 
 
-MHA_SELF_VARIANT = int(os.environ.get("MMAE_MHA_VARIANT", "0"))   # tuning knob (A/B runs of bench.py): variant of mha_self calls
+MHA_SELF_VARIANT = 0       # variant of mha_self calls that pass none (0 = product kernels; tools/tuning_env.py sets it for A/B runs)
 
 
-def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv", variant: Optional[int] = None) -> torch.Tensor:
+def _variant_word(variant: int, hpb: int) -> int:
+    """csrc/mmae_internal.h: bits 0..7 of a non-negative variant name the kernel, bits 8..11 the heads one workgroup of the
+    sample-head kernels walks (0: chosen from (B, H) as the product path does)."""
+    assert 0 <= hpb < 16
+    return variant if (variant < 0 or not hpb) else (variant | (hpb << 8))
+
+
+def mha_self(qkv: torch.Tensor, H: int, dh: int, seg: Segments, scale: float, order: str = "qkv", variant: Optional[int] = None,
+             hpb: int = 0) -> torch.Tensor:
     """Self attention on a fused projection output qkv (rows, 3*H*dh) laid out [q | k | v] column blocks.
-    variant != 0: test / tuning kernels through csrc/mmae_internal.h (per call, no global state)."""
+    variant != 0 / hpb != 0: test / tuning kernels through csrc/mmae_internal.h (per call, no global state)."""
     variant = MHA_SELF_VARIANT if variant is None else variant
     if variant and dh != 64:
         variant = 0
     I = H * dh
-    return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0, variant)
+    return _MHA.apply(qkv, None, 0, I, 2 * I, H, dh, seg, seg, scale, 0, _variant_word(variant, hpb))
 
 
 def mha_cross(q: torch.Tensor, kv: torch.Tensor, H: int, dh: int, qseg: Segments, kseg: Segments, scale: float,
-              empty_mode: int = 0, variant: int = 0) -> torch.Tensor:
+              empty_mode: int = 0, variant: int = 0, hpb: int = 0) -> torch.Tensor:
     """q (rows_q, H*dh), kv (rows_k, 2*H*dh) = [k | v]."""
-    return _MHA.apply(q, kv, 0, 0, H * dh, H, dh, qseg, kseg, scale, empty_mode, variant)
+    return _MHA.apply(q, kv, 0, 0, H * dh, H, dh, qseg, kseg, scale, empty_mode, _variant_word(variant, hpb))
 
 
 # ------------------------------------------------------------------------------------------------ modality attention
@@ -771,7 +822,7 @@ class _GELU(torch.autograd.Function):
 geglu = _GEGLU.apply
 gelu = _GELU.apply
 
-FF_CHUNKS = int(os.environ.get("MMAE_FF_CHUNKS", "1"))      # see _FeedForwardGEGLU: 2 was measured, no net gain
+FF_CHUNKS = 1      # see _FeedForwardGEGLU: 2 was measured, no net gain
 
 
 def _row_chunks(rows: int, n: int):

@@ -216,9 +216,11 @@ class PretrainStep:
                 held = {id(p) for p in optimizer.params}
                 bal = [p for p in bal if id(p) not in held]
                 if bal:
+                    # capturable: the step counts live on the device, so a skipped step can be undone without a host sync
                     self.balancer_opt = torch.optim.AdamW(bal, lr=optimizer.param_groups[0]["lr"] * balancer_lr_scale,
                                                           betas=tuple(optimizer.betas), eps=optimizer.eps,
-                                                          weight_decay=optimizer.param_groups[0]["weight_decay"])
+                                                          weight_decay=optimizer.param_groups[0]["weight_decay"],
+                                                          capturable=all(p.is_cuda for p in bal))
             else:
                 held = {id(p) for g in optimizer.param_groups for p in g["params"]}
                 if any(id(p) not in held for p in bal):
@@ -235,7 +237,7 @@ class PretrainStep:
                 for g in self.balancer_opt.param_groups:       # follows the engine's schedule (the driver sets lr per step)
                     g["lr"] = self.opt.param_groups[0]["lr"] * self.balancer_lr_scale
                     g["weight_decay"] = self.opt.param_groups[0]["weight_decay"]
-                self.balancer_opt.step()
+                self._balancer_step(self.opt.skip_flag())
             return
         params = [p for g in self.opt.param_groups for p in g['params'] if p.grad is not None]
         if self.clip_grad is not None:
@@ -245,6 +247,31 @@ class PretrainStep:
             if float(norm) >= self.skip_grad:                                     # native_scaler.py:29-32
                 return
         self.opt.step()
+
+    def _balancer_step(self, skip):
+        """Step the companion AdamW of the loss balancer under the SAME decision as the model's step: the reference holds both in
+        one optimizer, so GradScaler's non-finite guard / the skip threshold skip log_vars and their moments too
+        (native_scaler.py:24-37, optim_factory.py:136-150) -- otherwise one NaN loss would leave log_vars NaN for good and every
+        skipped step would advance their bias correction.  `skip`: the engine's device flag (None: uncontrolled step).  The
+        update is taken and, where the flag is set, undone by torch.where on the few scalars involved -- no host sync."""
+        opt = self.balancer_opt
+        if skip is None:
+            opt.step()
+            return
+        snap = []
+        for g in opt.param_groups:
+            for p in g["params"]:
+                st = opt.state.get(p, {})
+                snap.append((p, p.detach().clone(), {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}))
+        opt.step()
+        for p, old, st_old in snap:
+            sk = skip.to(p.device)
+            p.data.copy_(torch.where(sk, old, p.data))
+            for k, v in opt.state.get(p, {}).items():
+                if torch.is_tensor(v):
+                    o = st_old.get(k)
+                    o = torch.zeros_like(v) if o is None else o          # first step skipped: back to the fresh state
+                    v.copy_(torch.where(skip.to(v.device), o, v))
 
     def __call__(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None):
         x = {t: v for t, v in tasks_dict.items() if t in self.in_domains}
@@ -262,12 +289,14 @@ class PretrainStep:
         ops.join_wgrad_stream()
         if self.reducer is not None:
             self.reducer.finish()
-            if self.balancer_opt is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            if self.balancer_opt is not None and torch.distributed.is_initialized() and \
+                    torch.distributed.get_world_size(getattr(self.reducer, "group", None)) > 1:
+                grp = getattr(self.reducer, "group", None)       # the reducer's process group, not the default one
                 for g in self.balancer_opt.param_groups:       # a handful of scalars: one tiny all-reduce each
                     for q in g["params"]:
                         if q.grad is not None:
-                            torch.distributed.all_reduce(q.grad)
-                            q.grad.div_(torch.distributed.get_world_size())
+                            torch.distributed.all_reduce(q.grad, group=grp)
+                            q.grad.div_(torch.distributed.get_world_size(grp))
         self._optimizer_step()
         return {'loss': loss.detach(), 'loss_contra': loss_contra.detach(),
                 **{k + '_loss': v.detach() for k, v in task_losses.items()}}

@@ -12,12 +12,23 @@ instead of a hand-picked relaxation:
           HIP/anchor error ratios have median ~1; a few of the several hundred tensors -- 768-element vectors at B = 2 -- reach
           1.6-2.2: two different bf16 evaluations of one tensor are two draws of rounding noise, so single small tensors get a
           wider statistical band than the aggregate, which must meet 1.5x.)
-    All numbers are reported (pytest -s prints the summary; it is part of every assertion message).
+    All numbers are reported (pytest -s prints the summary; it is part of every assertion message) AND logged: every compare()
+    call appends one JSON line to gpurun_out/parity_log.jsonl (test id, mode, how many outputs / gradient tensors sit above the
+    plain tolerance, the worst HIP/anchor ratio, the aggregate gradient rel-L2 of HIP and of the anchor), which
+    tools/make_profiles.sh folds into the tracked profiles/rNN_parity.md -- so the verdicts can be inspected after `pytest -q`.
+    STRICT clause (no anchor): every loss scalar (`loss`, `loss/<domain>`, `loss_contra`) must be within the plain 1e-2, and
+    every prediction image (`pred/<domain>`) within the plain 1e-2 in RELATIVE L2 -- those are large reductions / full images, not
+    small-tensor rounding noise.  (The max-abs error of a prediction image -- one worst pixel out of 1e4..2e5, relative to
+    max|ref| -- stays under rule (1): measured on the first run of this clause it is 1.0-1.4e-2 on the tiny configurations where
+    the reference's OWN bf16 arithmetic, the anchor, gives 0.8-1.3e-2; a bar the reference's arithmetic fails is not a parity bar.
+    Both figures of every prediction are logged.)
 
 Metrics: outputs / losses -- max-abs error relative to max|ref| (the contract's metric); gradients in bf16 mode -- relative
 L2 (single elements of an L1-head gradient are sign functions of bf16-rounded residuals and legitimately flip; the anchor
 run shows the same flips), in fp32 mode max-abs relative like the outputs.
 """
+import json
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -25,6 +36,22 @@ import torch
 from oracle import mmae_oracle as O
 
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARITY_LOG = os.environ.get("MMAE_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_log.jsonl"))
+
+
+def _is_strict(name: str) -> bool:
+    """Loss scalars: held to the plain tolerance (max-abs relative) whatever the anchor says."""
+    return name in ("loss", "loss_contra") or name.startswith("loss/")
+
+
+def _log_line(rec: dict):
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass                                    # a read-only checkout must not fail the parity verdict itself
 
 
 def leaf_params(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -129,7 +156,7 @@ def compare(got: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], anchor: 
     bf16 mode (anchor = the oracle's bf16 run): rules (1)-(3) of the module docstring."""
     grad_tol = 2 * tol if grad_tol is None else grad_tol
     assert set(k for k in ref if not k.startswith("grad/")) <= set(got), sorted(set(ref) - set(got))[:5]
-    bad, rows = [], []
+    bad, rows, pred_l2 = [], [], []
     for name, r in ref.items():
         is_grad = name.startswith("grad/")
         if name not in got:
@@ -150,15 +177,34 @@ def compare(got: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], anchor: 
             metric = _l2rel if is_grad else _maxrel
             e, ea = metric(g, r), metric(anchor[name], r)
             k = tensor_slack if is_grad else slack
-            lim = max(tol, k * ea)
+            lim = tol if _is_strict(name) else max(tol, k * ea)
             rows.append((name, e, ea, lim))
-            if e > lim:
+            if e > lim and _is_strict(name):
+                bad.append("%s: err %.3e > %.0e (strict: loss scalar, no anchor; reference-bf16 %.3e)" % (name, e, tol, ea))
+            elif e > lim:
                 bad.append("%s: err %.3e > max(%.0e, %.1f x reference-bf16 %.3e)" % (name, e, tol, k, ea))
+            if name.startswith("pred/"):                  # strict, no anchor: the image as a whole
+                el2 = _l2rel(g, r)
+                pred_l2.append((name, el2, _l2rel(anchor[name], r), e, ea))
+                if el2 > tol:
+                    bad.append("%s: rel L2 %.3e > %.0e (strict: prediction image, no anchor)" % (name, el2, tol))
     for name, g in got.items():                           # gradients the reference does not have must be absent / zero
         if name.startswith("grad/") and name not in ref:
             if float(g.abs().max()) != 0.0:
                 bad.append("%s: gradient where the reference has none" % name)
     summary = ""
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" (")[0], "mode": "fp32" if anchor is None else "bf16-anchored",
+           "tol": tol, "tensors": len(rows), "failed": len(bad)}
+    outs_ = [r for r in rows if not r[0].startswith("grad/")]
+    grads_ = [r for r in rows if r[0].startswith("grad/")]
+    rec["outputs"] = len(outs_); rec["outputs_above_tol"] = sum(1 for r in outs_ if r[1] > tol)
+    rec["max_output_err"] = max((r[1] for r in outs_), default=0.0)
+    rec["strict_max_err"] = max((r[1] for r in outs_ if _is_strict(r[0])), default=0.0)
+    if pred_l2:
+        rec["pred_rel_l2_max"] = max(x[1] for x in pred_l2); rec["pred_rel_l2_max_anchor"] = max(x[2] for x in pred_l2)
+        rec["pred_maxabs_max"] = max(x[3] for x in pred_l2); rec["pred_maxabs_max_anchor"] = max(x[4] for x in pred_l2)
+    rec["grad_tensors"] = len(grads_); rec["grad_tensors_above_tol"] = sum(1 for r in grads_ if r[1] > (tol if anchor is not None else grad_tol))
+    rec["max_grad_err"] = max((r[1] for r in grads_), default=0.0)
     if anchor is not None:
         gnames = [n for n in ref if n.startswith("grad/") and n in got and n in anchor]
         cat = lambda d: torch.cat([d[n].flatten() for n in gnames]) if gnames else torch.zeros(1, dtype=torch.float64)
@@ -175,7 +221,12 @@ def compare(got: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], anchor: 
                       ratios[len(ratios) // 2] if ratios else 0.0, ratios[int(0.9 * (len(ratios) - 1))] if ratios else 0.0,
                       ratios[-1] if ratios else 0.0,
                       ", ".join("%s %.2f (%.2e vs %.2e)" % (r[0], r[1] / max(r[2], 1e-30), r[1], r[2]) for r in worst)))
+        rec.update(grad_rel_l2_hip=e_all, grad_rel_l2_anchor=ea_all, worst_ratio=ratios[-1] if ratios else 0.0,
+                   median_ratio=ratios[len(ratios) // 2] if ratios else 0.0,
+                   worst_tensor=worst[0][0] if worst else "", max_output_err_anchor=max((r[2] for r in outs_), default=0.0))
         if verbose:
             print("\n[parity] " + summary)
+    rec["failed"] = len(bad)
+    _log_line(rec)
     assert not bad, "%d tensors out of tolerance: %s || %s" % (len(bad), bad[:8], summary)
     return rows

@@ -12,15 +12,20 @@ from tests.test_gpu_kernels import COLSUM, DEV, GRAD, close, dense_attention_ref
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4),
-                                       (torch.bfloat16, 5), (torch.bfloat16, 23)])
-def test_fuzz_attention_segments(T, variant):
+# hpb: heads one workgroup of the sample-head kernels walks (csrc/mmae_internal.h); 0 = the product's choice (1 at these batch
+# sizes).  With hpb = 2 / 8 every case runs H = 8 -- the head loop and the cross-head prefetch of the bench configuration.
+@pytest.mark.parametrize("T,variant,hpb", [(torch.float32, 0, 0), (torch.bfloat16, 0, 0), (torch.bfloat16, 2, 0), (torch.bfloat16, 4, 0),
+                                           (torch.bfloat16, 5, 0), (torch.bfloat16, 23, 0), (torch.bfloat16, 0, 1), (torch.bfloat16, 0, 2),
+                                           (torch.bfloat16, 0, 8), (torch.bfloat16, 5, 2), (torch.bfloat16, 5, 8)])
+def test_fuzz_attention_segments(T, variant, hpb):
     from incomplete_multimodal_fusion_amd import ops
     rng = random.Random(1234)
     torch.manual_seed(77)
     for case in range(24):
-        dh = rng.choice([32, 64]) if variant == 0 else 64
+        dh = rng.choice([32, 64]) if (variant == 0 and not hpb) else 64
         H = rng.choice([1, 2, 3, 8]); nseg = rng.randint(1, 5); B = rng.randint(1, 4)
+        if hpb:
+            H = 8
         empty_mode = rng.choice([0, 1]); same = rng.random() < 0.5
         pick = lambda: rng.choice([0, 0, 1, 7, 63, 64, 65, 100, 128, 129, 191, 200, 257])
         qlens = torch.tensor([[pick() for _ in range(nseg)] for _ in range(B)], dtype=torch.int32)
@@ -45,7 +50,7 @@ def test_fuzz_attention_segments(T, variant):
         qseg = ops.Segments(qst.to(DEV), qlens.to(DEV), max(int(qlens.sum(1).max()), 1), covers_all=gap == 0 and nq == int(qlens.sum()))
         kseg = ops.Segments(kst.to(DEV), klens.to(DEV), max(int(klens.sum(1).max()), 1), covers_all=gap == 0 and nk == int(klens.sum()))
         scale = dh ** -0.5
-        out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant)
+        out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant, hpb=hpb)
         out.backward(g.to(DEV, T))
         q64 = qd.detach().cpu().double().reshape(nq, H, dh).requires_grad_()
         kv64 = kvd.detach().cpu().double()

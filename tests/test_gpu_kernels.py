@@ -285,14 +285,20 @@ def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
 
 # variant: kernel variant of csrc/mmae_internal.h (0 = what the product ABI runs: the 32x32x16 forward for dh 64; 2 = the
 # 16x16x32 forward of round 1; 4 = 32x32x16 with 256-query tiles)
-@pytest.mark.parametrize("T,dh,variant", [(torch.float32, 64, 0), (torch.float32, 32, 0), (torch.bfloat16, 64, 0),
-                                          (torch.bfloat16, 32, 0), (torch.bfloat16, 64, 2), (torch.bfloat16, 64, 4),
-                                          (torch.bfloat16, 64, 5), (torch.bfloat16, 64, 23)])
+# H, hpb: heads, and how many of them ONE workgroup of the sample-head kernels walks (0 = the product's choice, which is 1 at
+# these batch sizes).  The bench shape (B = 256, H = 8) runs hpb = 8: head loop, K/V ring prefetch ACROSS head boundaries;
+# hpb 2 / 8 at H = 8 reach exactly that code here (forward + dK/dV with variant 0, the query-stationary dQ with variant 5).
+HPB_CASES = [(torch.bfloat16, 64, v, 8, hpb) for v in (0, 5) for hpb in (1, 2, 8)]
+
+
+@pytest.mark.parametrize("T,dh,variant,H,hpb", [(torch.float32, 64, 0, 3, 0), (torch.float32, 32, 0, 3, 0), (torch.bfloat16, 64, 0, 3, 0),
+                                                (torch.bfloat16, 32, 0, 3, 0), (torch.bfloat16, 64, 2, 3, 0), (torch.bfloat16, 64, 4, 3, 0),
+                                                (torch.bfloat16, 64, 5, 3, 0), (torch.bfloat16, 64, 23, 3, 0)] + HPB_CASES)
 @pytest.mark.parametrize("empty_mode", [0, 1])
-def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
+def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant, H, hpb):
     from incomplete_multimodal_fusion_amd import ops
     torch.manual_seed(3)
-    H, nseg = 3, 4
+    nseg = 4
     I = H * dh
     # per-sample different lengths, crossing 64-row tile boundaries, with empty segments (dropped modalities)
     qlens = torch.tensor([[70, 1, 130, 65], [0, 64, 63, 129], [5, 0, 0, 3]], dtype=torch.int32)
@@ -312,7 +318,7 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     qseg = ops.Segments(qst.to(DEV), qlens.to(DEV), int(qlens.sum(1).max()))
     kseg = ops.Segments(kst.to(DEV), klens.to(DEV), int(klens.sum(1).max()))
     scale = dh ** -0.5
-    out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant)
+    out = ops.mha_cross(qd, kvd, H, dh, qseg, kseg, scale, empty_mode, variant=variant, hpb=hpb)
     out.backward(g.to(DEV, T))
     # reference on what the kernel actually saw (bf16-rounded inputs), fp64
     q64 = qd.detach().cpu().double().reshape(nq, H, dh).requires_grad_()
@@ -327,32 +333,97 @@ def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant):
     close(kvd.grad[:, I:], v64.grad.reshape(nk, I), tol * GRAD, "dv")
 
 
-@pytest.mark.parametrize("T,variant", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 2), (torch.bfloat16, 4),
-                                       (torch.bfloat16, 5), (torch.bfloat16, 23)])
+@pytest.mark.parametrize("T,variant,H,hpb", [(torch.float32, 0, 1, 0), (torch.bfloat16, 0, 1, 0), (torch.bfloat16, 2, 1, 0),
+                                             (torch.bfloat16, 4, 1, 0), (torch.bfloat16, 5, 1, 0), (torch.bfloat16, 23, 1, 0)] +
+                         [(torch.bfloat16, v, 8, hpb) for v in (0, 5) for hpb in (1, 2, 8)])
 @pytest.mark.parametrize("shift", [0.0, -40.0])
-def test_mha_online_softmax_rescale_branch(T, variant, shift):
+def test_mha_online_softmax_rescale_branch(T, variant, shift, H, hpb):
     """Spike one key per tile so that the running max jumps at chosen tiles (forces the rescale path; the 32x32x16 forward
     defers the rescale until a row outgrows its reference by 2^6, so spikes below AND above that threshold are used).
     shift: every score of query 10 moved far below zero (a constant along the key axis: softmax unchanged) -- the running
-    reference must follow the data, not sit at 0."""
+    reference must follow the data, not sit at 0.  H = 8: every head has its own data and its own spike amplitudes (head h
+    scales them by 1 + h / 4), walked hpb heads per workgroup (see HPB_CASES)."""
     from incomplete_multimodal_fusion_amd import ops
     torch.manual_seed(5)
-    H, dh, n = 1, 64, 300
-    q = torch.randn(n, dh); k = torch.randn(n, dh) * 0.1; v = torch.randn(n, dh)
-    for j, amp in ((30, 1.5), (70, 4.0), (140, 9.0), (299, 20.0)):
-        k[j] = q[10] * amp / q[10].norm()
-    if shift:
-        k = k + shift * dh ** 0.5 * q[10][None] / (q[10] @ q[10])       # adds `shift` to every scaled score of query 10
-    qkv = torch.cat([q, k, v], dim=1).to(DEV, T).requires_grad_()
+    dh, n = 64, 300
+    q = torch.randn(n, H, dh); k = torch.randn(n, H, dh) * 0.1; v = torch.randn(n, H, dh)
+    for h in range(H):
+        q10 = q[10, h]
+        for j, amp in ((30, 1.5), (70, 4.0), (140, 9.0), (299, 20.0)):
+            k[j, h] = q10 * (amp * (1 + h / 4)) / q10.norm()
+        if shift:
+            k[:, h] = k[:, h] + shift * dh ** 0.5 * q10[None] / (q10 @ q10)   # adds `shift` to every scaled score of query 10
+    I = H * dh
+    qkv = torch.cat([q.reshape(n, I), k.reshape(n, I), v.reshape(n, I)], dim=1).to(DEV, T).requires_grad_()
     seg = ops.Segments.dense(1, n, DEV)
-    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variant)
+    out = ops.mha_self(qkv, H, dh, seg, dh ** -0.5, variant=variant, hpb=hpb)
     out.sum().backward()
     x = qkv.detach().cpu().double().requires_grad_()
-    qq, kk, vv = x[:, :dh], x[:, dh:2 * dh], x[:, 2 * dh:]
-    ref = torch.softmax(qq @ kk.t() * dh ** -0.5, dim=-1) @ vv
+    qq, kk, vv = (x[:, i * I:(i + 1) * I].reshape(n, H, dh) for i in range(3))
+    p = torch.softmax(torch.einsum("ihd,jhd->hij", qq, kk) * dh ** -0.5, dim=-1)
+    ref = torch.einsum("hij,jhd->ihd", p, vv).reshape(n, I)
     ref.sum().backward()
     tol = 2e-5 if T == torch.float32 else 1e-2
     close(out, ref, tol, "out"); close(qkv.grad, x.grad, tol * GRAD, "grads")
+
+
+def _dirichlet_segments(B, N, P, M, gen):
+    """Per-sample segment lengths as the bench draws them: Dirichlet(1) shares of N kept tokens over M modalities (largest-remainder
+    rounding so each row sums to N, capped at P) + P fusion rows.  -> (start, length) int32 (B, M + 1), rows packed per sample."""
+    w = torch.distributions.Dirichlet(torch.ones(M)).sample((B,))
+    lens = torch.floor(w * N).to(torch.int64)
+    for b in range(B):
+        while int(lens[b].sum()) < N:
+            lens[b, int(torch.argmin(lens[b] - w[b] * N))] += 1
+        while int(lens[b].max()) > P:                                   # a modality has only P patches
+            i = int(lens[b].argmax()); ex = int(lens[b, i]) - P; lens[b, i] = P
+            lens[b, int(lens[b].argmin())] += ex
+    lens = torch.cat([lens, torch.full((B, 1), P, dtype=torch.int64)], dim=1).to(torch.int32)
+    flat = lens.reshape(-1).to(torch.int64)
+    start = (torch.cumsum(flat, 0) - flat).reshape(B, M + 1).to(torch.int32)
+    return start, lens
+
+
+@pytest.mark.parametrize("variant", [0, 5])
+def test_mha_bench_shape_dispatch_vs_fp64(variant):
+    """The configuration bench.py runs: B = 256 samples x H = 8 heads x dh 64, every sample Dirichlet-ragged
+    modality segments summing to 384 + 256 fusion rows, bf16, the PRODUCT dispatch (variant 0: one workgroup per sample walks all
+    eight heads -- hpb = 8 by the library's own choice, K/V ring prefetched across head boundaries; forward = mha_sh_fwd_kernel,
+    dK/dV = mha_sh_dkdv_kernel, dQ = the tile-per-block kernel; variant 5: the query-stationary dQ).  Checked against the fp64
+    dense restatement of the segment rule on 12 samples: the first, the last, the most skewed split and 9 random ones -- outputs,
+    dQ, dK, dV.  The other samples are held to finiteness and to the row-sum property of softmax (V = 1 column check below)."""
+    from incomplete_multimodal_fusion_amd import ops
+    gen = torch.manual_seed(41)
+    B, H, dh, N, P, M = 256, 8, 64, 384, 256, 3
+    I = H * dh
+    st, ln = _dirichlet_segments(B, N, P, M, gen)
+    rows = B * (N + P)
+    assert int(ln.sum()) == rows and int(ln[:, :M].sum(1).min()) == N
+    qkv = torch.randn(rows, 3 * I, device=DEV).to(torch.bfloat16)
+    qkv[:, 2 * I] = 1.0                                        # v[:, head 0, dim 0] = 1: that output column must be exactly ~1
+    g = torch.randn(rows, I, device=DEV).to(torch.bfloat16)
+    x = qkv.clone().requires_grad_()
+    seg = ops.Segments(st.to(DEV), ln.to(DEV), N + P)
+    out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
+    out.backward(g)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(x.grad.float()).all()
+    close(out[:, 0].float(), torch.ones(rows), 1e-2, "softmax rows sum to one (all samples)")
+    skew = int((ln[:, :M].max(1).values).argmax())
+    pick = sorted(set([0, B - 1, skew] + torch.randperm(B)[:9].tolist()))
+    for b in pick:
+        r0, r1 = int(st[b, 0]), int(st[b, 0]) + N + P
+        xs = x.detach()[r0:r1].cpu().double()
+        q64 = xs[:, :I].reshape(-1, H, dh).clone().requires_grad_()
+        k64 = xs[:, I:2 * I].reshape(-1, H, dh).clone().requires_grad_()
+        v64 = xs[:, 2 * I:].reshape(-1, H, dh).clone().requires_grad_()
+        lst = (st[b:b + 1] - r0, ln[b:b + 1])
+        ref = dense_attention_ref(q64, k64, v64, lst, lst, dh ** -0.5, 0)
+        ref.backward(g[r0:r1].cpu().double().reshape(-1, H, dh))
+        tag = " sample %d lens %s" % (b, ln[b].tolist())
+        close(out[r0:r1], ref.reshape(-1, I), 1e-2, "out" + tag)
+        close(x.grad[r0:r1, :I], q64.grad.reshape(-1, I), 1e-2 * GRAD, "dq" + tag)
+        close(x.grad[r0:r1, I:2 * I], k64.grad.reshape(-1, I), 1e-2 * GRAD, "dk" + tag)
+        close(x.grad[r0:r1, 2 * I:], v64.grad.reshape(-1, I), 1e-2 * GRAD, "dv" + tag)
 
 
 # ---------------------------------------------------------------------------------------------- row kernels, big + odd sizes
@@ -544,8 +615,8 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     g = torch.randn(r, I, device=DEV).to(torch.bfloat16)
     res = []
     # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path (dh 64: 32x32x16 forward), 2: the round-1
-    # 16x16x32 forward, 4: 256-query tiles, 9: the stamped diagnostic build
-    for variant in ((-1, 0, 2, 4, 5, 9) if dh == 64 else (-1, 0)):
+    # 16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ (the stamped diagnostic builds 8 / 9 exist in `make DIAG=1` only)
+    for variant in ((-1, 0, 2, 4, 5) if dh == 64 else (-1, 0)):
         x = qkv.clone().requires_grad_()
         out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)
@@ -614,3 +685,163 @@ def test_dual_double_layernorm_equals_two_passes(D, T, n0):
             assert a is None and b is None, n
             continue
         close(a, b, 1e-6 if n in ("z", "zb", "x0_new", "x1_new") else tol, n)
+
+
+# ---------------------------------------------------------------------------------------------- row kernels at the bench's scale
+# the persistent multi-row loops of add_ln_{fwd,bwd}[_dual]_fast_kernel / add_ln_fwd_cast (768-block grid, several
+# rows per wave, gamma in LDS) and the one-pass GEGLU grids only run at bench-scale row counts.  Checker: the oracle's fp64
+# zorro_layernorm composition (zorro_utils.py:103-110 twice, :238-239 with :176 / :124) evaluated on the CPU in row chunks (rows are
+# independent; the gamma gradients are summed over the chunks), compared chunk by chunk so no full-size fp64 tensor is ever held.
+CH = 16384
+
+
+def _ln_pair_ref_chunks(x, delta, gammas, gys, gup, r0, r1):
+    """One chunk of rows [r0, r1): x fp32, delta bf16 or None, gammas = [(g1, g2 or None), ...] (one pair per normalised output),
+    gys = upstream gradients of those outputs (or None), gup = upstream gradient of x_new (or None).
+    -> (x_new, [y_i], gx, per-pair (dg1, dg2)) in fp64."""
+    X = x[r0:r1].double().requires_grad_()
+    xn = X if delta is None else X + delta[r0:r1].double()
+    leaves, ys, loss = [], [], 0
+    for (g1, g2), gy in zip(gammas, gys):
+        a = g1.double().requires_grad_(); b = None if g2 is None else g2.double().requires_grad_()
+        y = O.zorro_layernorm(xn, a)
+        if b is not None:
+            y = O.zorro_layernorm(y, b)
+        ys.append(y.detach()); leaves.append((a, b))
+        if gy is not None:
+            loss = loss + (y * gy[r0:r1].double()).sum()
+    if gup is not None:
+        loss = loss + (xn * gup[r0:r1].double()).sum()
+    loss.backward()
+    return xn.detach(), ys, X.grad, [(a.grad, None if b is None else b.grad) for a, b in leaves]
+
+
+@pytest.mark.parametrize("rows_mod,rows_fus,D", [(98304, 65536, 768), (40000, 25536, 1024)])
+def test_add_double_ln_bench_scale_vs_oracle(rows_mod, rows_fus, D):
+    """The encoder's residual pass as the bench runs it: two parts (B*N modality rows, B*P fusion rows; 163 840 x 768 at ViT-B with
+    B = 256, 65 536 x 1024 for ViT-L), bf16 delta and output, both residual outputs consumed -- forward + backward."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(21)
+    rows = rows_mod + rows_fus
+    x = torch.randn(rows, D) * 2 + 0.3
+    delta = torch.randn(rows, D).to(torch.bfloat16)
+    g1 = torch.rand(D) + 0.5; g2 = torch.rand(D) + 0.5
+    gy = torch.randn(rows, D).to(torch.bfloat16); gup = torch.randn(rows, D)
+    xs = [x[:rows_mod].to(DEV).requires_grad_(), x[rows_mod:].to(DEV).requires_grad_()]
+    dd = delta.to(DEV).requires_grad_(); G1 = g1.to(DEV).requires_grad_(); G2 = g2.to(DEV).requires_grad_()
+    (n1, n2), y = ops.parts_add_ln(xs, dd, [0, rows_mod], G1, None, G2, None, out_dtype=torch.bfloat16)
+    gupd = gup.to(DEV)
+    ((y.float() * gy.to(DEV).float()).sum() + (n1 * gupd[:rows_mod]).sum() + (n2 * gupd[rows_mod:]).sum()).backward()
+    xn_d = torch.cat([n1, n2]).detach().cpu(); y_d = y.detach().float().cpu()
+    gx_d = torch.cat([xs[0].grad, xs[1].grad]).cpu(); gd_d = dd.grad.float().cpu()
+    dg1 = torch.zeros(D, dtype=torch.float64); dg2 = torch.zeros(D, dtype=torch.float64)
+    for r0 in range(0, rows, CH):
+        r1 = min(rows, r0 + CH)
+        xn, (yr,), gx, ((a, b),) = _ln_pair_ref_chunks(x, delta, [(g1, g2)], [gy], gup, r0, r1)
+        tag = " rows %d..%d" % (r0, r1)
+        close(xn_d[r0:r1], xn, 1e-6, "x_new" + tag); close(y_d[r0:r1], yr, 1e-2, "y" + tag)
+        close(gx_d[r0:r1], gx, 1e-2 * GRAD, "gx" + tag); close(gd_d[r0:r1], gx, 1e-2 * GRAD, "gdelta" + tag)
+        dg1 += a; dg2 += b
+    close(G1.grad, dg1, 1e-2 * COLSUM, "dgamma1"); close(G2.grad, dg2, 1e-2 * COLSUM, "dgamma2")
+
+
+def test_dual_double_ln_bench_scale_vs_oracle():
+    """The modality rows of one layer normalised with BOTH gamma pairs in one pass (mmae_add_ln_fwd_dual / _bwd_dual) at 98 304 rows,
+    the second matrix completed with the 65 536 fusion rows by parts_add_ln(y_into=...) -- the call pattern of
+    multimae_crossattn.py's layer loop at B = 256 -- against the fp64 composition, forward and backward."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(22)
+    D, n0, n1 = 768, 98304, 65536
+    T = torch.bfloat16
+    x0 = torch.randn(n0, D) * 1.5; x1 = torch.randn(n1, D) - 0.2
+    delta = torch.randn(n0 + n1, D).to(T); f = torch.randn(n1, D).to(T)
+    ga = [torch.rand(D) + 0.5 for _ in range(2)]; gb = [torch.rand(D) + 0.5 for _ in range(2)]
+    w_z = torch.randn(n0 + n1, D).to(T); w_zb = torch.randn(n0 + n1, D).to(T)
+    w0 = torch.randn(n0, D); w1 = torch.randn(n1, D)
+    a0, a1 = x0.to(DEV).requires_grad_(), x1.to(DEV).requires_grad_()
+    dl, ff = delta.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    GA = [g.to(DEV).requires_grad_() for g in ga]; GB = [g.to(DEV).requires_grad_() for g in gb]
+    zb = torch.empty(n0 + n1, D, dtype=T, device=DEV)
+    (y0, y1), z, zb = ops.parts_add_ln([a0, a1], dl, [0, n0], GA[0], None, GA[1], None, out_dtype=T, dual=(0, GB[0], GB[1], zb, 0))
+    (y1b,), zb = ops.parts_add_ln([y1], ff, [0], GB[0], None, GB[1], None, out_dtype=T, y_into=(zb, n0))
+    loss = (z.float() * w_z.to(DEV).float()).sum() + (zb.float() * w_zb.to(DEV).float()).sum() + (y0 * w0.to(DEV)).sum() + \
+        (y1b * w1.to(DEV)).sum()
+    loss.backward()
+    got = {k: v.detach().float().cpu() for k, v in dict(z=z, zb=zb, y0=y0, y1b=y1b, da0=a0.grad, da1=a1.grad, ddl=dl.grad, dff=ff.grad).items()}
+    acc = [torch.zeros(D, dtype=torch.float64) for _ in range(4)]
+    # modality rows: x0 + delta -> pair A (into z) and pair B (into zb); residual output y0 consumed with w0
+    for r0 in range(0, n0, CH):
+        r1 = min(n0, r0 + CH)
+        xn, (ya, yb), gx, ((a1_, a2_), (b1_, b2_)) = _ln_pair_ref_chunks(x0, delta[:n0], [(ga[0], ga[1]), (gb[0], gb[1])],
+                                                                         [w_z[:n0], w_zb[:n0]], w0, r0, r1)
+        tag = " modality rows %d..%d" % (r0, r1)
+        close(got["y0"][r0:r1], xn, 1e-6, "x_new" + tag); close(got["z"][r0:r1], ya, 1e-2, "z" + tag); close(got["zb"][r0:r1], yb, 1e-2, "zb" + tag)
+        close(got["da0"][r0:r1], gx, 1e-2 * GRAD, "dx0" + tag); close(got["ddl"][r0:r1], gx, 1e-2 * GRAD, "ddelta" + tag)
+        for t, g in zip(acc, (a1_, a2_, b1_, b2_)):
+            t += g
+    # fusion rows: y1 = x1 + delta -> pair A (into z); y1b = y1 + f -> pair B (into zb); y1b consumed with w1
+    for r0 in range(0, n1, CH):
+        r1 = min(n1, r0 + CH)
+        X = x1[r0:r1].double().requires_grad_(); Dl = delta[n0 + r0:n0 + r1].double().requires_grad_(); F = f[r0:r1].double().requires_grad_()
+        lv = [g.double().requires_grad_() for g in (*ga, *gb)]
+        yy1 = X + Dl
+        za = O.zorro_layernorm(O.zorro_layernorm(yy1, lv[0]), lv[1])
+        yy1b = yy1 + F
+        zbb = O.zorro_layernorm(O.zorro_layernorm(yy1b, lv[2]), lv[3])
+        ((za * w_z[n0 + r0:n0 + r1].double()).sum() + (zbb * w_zb[n0 + r0:n0 + r1].double()).sum() + (yy1b * w1[r0:r1].double()).sum()).backward()
+        tag = " fusion rows %d..%d" % (r0, r1)
+        close(got["y1b"][r0:r1], yy1b, 1e-6, "x_new" + tag)
+        close(got["z"][n0 + r0:n0 + r1], za, 1e-2, "z" + tag); close(got["zb"][n0 + r0:n0 + r1], zbb, 1e-2, "zb" + tag)
+        close(got["da1"][r0:r1], X.grad, 1e-2 * GRAD, "dx1" + tag); close(got["ddl"][n0 + r0:n0 + r1], Dl.grad, 1e-2 * GRAD, "ddelta" + tag)
+        close(got["dff"][r0:r1], F.grad, 1e-2 * GRAD, "df" + tag)
+        for t, g in zip(acc, lv):
+            t += g.grad
+    for nm, G, r in zip(("dga1", "dga2", "dgb1", "dgb2"), (*GA, *GB), acc):
+        close(G.grad, r, 1e-2 * COLSUM, nm)
+
+
+def test_add_ln_cast_copy_bench_scale_vs_oracle():
+    """mmae_add_ln_fwd_cast at 163 840 x 768 (the final norm at B = 256): fp32 y + its bf16 copy, the copy's bf16 gradient alone."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(23)
+    D, ra, rb = 768, 98304, 65536
+    rows = ra + rb
+    x = torch.randn(rows, D) * 2 - 0.5
+    delta = torch.randn(rows, D).to(torch.bfloat16)
+    g1 = torch.rand(D) + 0.5
+    gyT = torch.randn(rows, D).to(torch.bfloat16)
+    xs = [x[:ra].to(DEV).requires_grad_(), x[ra:].to(DEV).requires_grad_()]
+    dd = delta.to(DEV).requires_grad_(); G1 = g1.to(DEV).requires_grad_()
+    res = ops.parts_add_ln(xs, dd, [0, ra], G1, None, None, None, out_dtype=torch.float32, cast_copy=True)
+    assert len(res) == 3 and res[2].dtype == torch.bfloat16
+    (_, _), y, yT = res
+    assert torch.equal(yT, y.to(torch.bfloat16)), "the copy must be the rounded fp32 output"
+    (yT.float() * gyT.to(DEV).float()).sum().backward()
+    y_d = y.detach().cpu(); gx_d = torch.cat([xs[0].grad, xs[1].grad]).cpu(); gd_d = dd.grad.float().cpu()
+    dg1 = torch.zeros(D, dtype=torch.float64)
+    for r0 in range(0, rows, CH):
+        r1 = min(rows, r0 + CH)
+        _, (yr,), gx, ((a, _),) = _ln_pair_ref_chunks(x, delta, [(g1, None)], [gyT], None, r0, r1)
+        tag = " rows %d..%d" % (r0, r1)
+        close(y_d[r0:r1], yr, 2e-5, "y" + tag); close(gx_d[r0:r1], gx, 2e-5 * GRAD, "gx" + tag)
+        close(gd_d[r0:r1], gx, 1e-2 * GRAD, "gdelta" + tag)
+        dg1 += a
+    close(G1.grad, dg1, 2e-5 * COLSUM, "dgamma1")
+
+
+def test_geglu_bench_scale_vs_oracle():
+    """GEGLU forward / backward at 163 840 x 2 048 (FeedForward of the encoder blocks at B = 256; zorro_utils.py:115-118), bf16,
+    against the exact-erf fp64 formula in row chunks -- every row of the one-pass grid, incl. the tail block."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(24)
+    rows, F = 163840, 2048
+    h = (torch.randn(rows, 2 * F, device=DEV) * 1.5).to(torch.bfloat16)
+    g = torch.randn(rows, F, device=DEV).to(torch.bfloat16)
+    hd = h.clone().requires_grad_()
+    out = ops.geglu(hd); out.backward(g)
+    for r0 in range(0, rows, CH):
+        r1 = min(rows, r0 + CH)
+        hr = h[r0:r1].cpu().double().requires_grad_()
+        ref = O.gelu_erf(hr[:, F:]) * hr[:, :F]
+        ref.backward(g[r0:r1].cpu().double())
+        close(out[r0:r1], ref, 1e-2, "geglu rows %d..%d" % (r0, r1)); close(hd.grad[r0:r1], hr.grad, 1e-2, "geglu grad rows %d..%d" % (r0, r1))

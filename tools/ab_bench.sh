@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/ab; mkdir -p $OUT
 R=${1:-3}
-ARGS="--steps ${AB_STEPS:-20} --warmup 4 --no-cpu-baseline --legs none ${AB_ARGS:-}"
+ARGS="--steps ${AB_STEPS:-20} --warmup 4 --no-cpu-baseline --legs none --tuning-env ${AB_ARGS:-}"
 for i in $(seq 1 $R); do
   for side in A B; do
     if [ $side = A ]; then E="$A_ENV"; else E="$B_ENV"; fi

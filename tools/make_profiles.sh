@@ -14,7 +14,9 @@ hdr() { echo "# $1"; echo; echo "Command (on the MI355X box, through tools/gpu_r
 { hdr "Round ${N#r} - kernel time of the bench step" "rocprofv3 --kernel-trace --stats --output-format csv"; python tools/prof_summary.py stats $S $STEPS; } > $DEST/${N}_kernel_stats.md
 cp $S $DEST/${N}_kernel_stats.csv
 { hdr "Round ${N#r} - HBM traffic per launch (two passes)" "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE --output-format csv"; python tools/prof_summary.py pmc $F $W; } > $DEST/${N}_pmc_hbm.md
-python tools/prof_summary.py json $F $W > $DEST/${N}_pmc_hbm.json
+python tools/prof_summary.py json $F $W $STEPS > $DEST/${N}_pmc_hbm.json
 { hdr "Round ${N#r} - SQ counters of the bench step, per kernel and whole step" "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv"; python tools/prof_summary.py sq $Q $STEPS; } > $DEST/${N}_sq_step.md
 python tools/prof_summary.py sq $Q $STEPS json > $DEST/${N}_sq_step.json
+# parity verdicts of the GPU tests of this call (tests/parity.py appends one JSON line per compare()), as a table
+if [ -f gpurun_out/parity_log.jsonl ]; then python tools/parity_table.py gpurun_out/parity_log.jsonl > $DEST/${N}_parity.md; fi
 echo "$S $Q $F $W"

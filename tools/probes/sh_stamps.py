@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Where does a tile iteration of the sample-head forward (csrc/mha_sh.hip) spend its cycles?  Runs the stamped diagnostic
-build (variant 8) on the bench shape and prints per-wave averages for the two wave roles.  Never a timing."""
+build (variant 8) on the bench shape and prints per-wave averages for the two wave roles.  Never a timing.
+Needs the diagnostic library: `make -C incomplete_multimodal_fusion_amd/csrc DIAG=1` (libmmae_hip_diag.so); this script selects it
+through MMAE_HIP_LIB before the package is imported."""
 import ctypes, os, sys
+os.environ.setdefault("MMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "incomplete_multimodal_fusion_amd", "csrc", "libmmae_hip_diag.so"))
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from incomplete_multimodal_fusion_amd import _lib, ops

@@ -3,7 +3,7 @@
 
   python tools/prof_summary.py stats  <kernel_stats.csv> <steps> > profiles/rNN_kernel_stats.md
   python tools/prof_summary.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_hbm.md
-  python tools/prof_summary.py json   <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_hbm.json
+  python tools/prof_summary.py json   <fetch counter_collection.csv> <write counter_collection.csv> [steps] > profiles/rNN_pmc_hbm.json
   python tools/prof_summary.py sq     <SQ counter_collection.csv> <steps> [json] > profiles/rNN_sq_step.md | .json
 
 PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
@@ -46,10 +46,16 @@ def pmc(fetch, write):
         print("| `%s` | %d | %.1f | %.1f | %.1f |" % (short(k), n, rd, wr, rd + wr))
 
 
-def pmc_json(fetch, write):
-    """Machine-readable form of `pmc` (bench.py reads it for roofline.traffic): corrected HBM bytes per launch per kernel."""
+def pmc_json(fetch, write, steps=0):
+    """Machine-readable form of `pmc` (bench.py reads it for roofline.traffic): corrected HBM bytes per launch per kernel, and the
+    kernel time per step of the FETCH pass (bench.py prints the traffic only while that is within 5 % of its own step time)."""
     import json
     d = {}
+    seen, ns = set(), 0
+    for x in csv.DictReader(open(fetch)):
+        if x["Dispatch_Id"] not in seen:
+            seen.add(x["Dispatch_Id"])
+            ns += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
     for path, name, key, scale in ((fetch, "FETCH_SIZE", "hbm_read_bytes_per_launch", 2 * 1024.0),
                                    (write, "WRITE_SIZE", "hbm_write_bytes_per_launch", 1024.0)):
         acc = collections.defaultdict(list)
@@ -62,7 +68,8 @@ def pmc_json(fetch, write):
             e["launches"] = max(e["launches"], len(v))
     print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 "
                                 "--warmup 1 --no-cpu-baseline`, B=256; bytes = 2*FETCH_SIZE*1024 (gfx950 half-count rule) + "
-                                "WRITE_SIZE*1024", "kernels": d}, indent=1))
+                                "WRITE_SIZE*1024", "kernel_ms_per_step": round(ns / 1e6 / steps, 2) if steps else None, "steps": steps,
+                      "kernels": d}, indent=1))
 
 
 def sq(path, steps, as_json=False):
@@ -126,7 +133,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "json":
-        pmc_json(sys.argv[2], sys.argv[3])
+        pmc_json(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], int(sys.argv[3]), len(sys.argv) > 4 and sys.argv[4] == "json")
     else:
