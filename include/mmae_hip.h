@@ -22,7 +22,9 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 3   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast */
+#define MMAE_ABI_VERSION 4   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
+                                mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
+                                mmae_mha_bwd_ws_floats */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -39,8 +41,10 @@ int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
                  float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
                  const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
                  int max_q_rows, int max_k_rows, float scale, int empty_mode, void* stream);
-/* backward of the above (autograd of the same lines).  delta_ws: (3, H, q_rows_total) fp32 scratch (delta and the row
- * constants handed from the dQ kernel to the dK/dV kernel). */
+/* backward of the above (autograd of the same lines).  delta_ws: mmae_mha_bwd_ws_floats(H, q_rows_total) fp32 scratch -- three
+ * (H, q_rows_total) planes: delta and the row constants handed from the dQ kernel to the dK/dV kernel (ABI 3; ABI 2 took ONE plane:
+ * an old-size buffer is a device out-of-bounds write, the library cannot check it -- size it with the function). */
+long mmae_mha_bwd_ws_floats(int H, long q_rows_total);
 int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                  const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
                  long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,
@@ -99,6 +103,9 @@ int mmae_add_ln_bwd_dual(int dtype_delta, int dtype_y, long rows, int D, const f
 /* ---- GEGLU (DSI-MM/zorro_utils.py:115-118): out[r, j] = gelu(h[r, F + j]) * h[r, j]; erf GELU, Phi to 1.5e-7 - */
 int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* stream);
 int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream);
+/* ---- DropPath / stochastic depth (DSI-MM/zorro_utils.py:69-84 on :238-239; MM/multimae_utils.py:105-132): out[r, :] =
+ * x[r, :] * row_scale[r], row_scale = floor(keep + u_sample) / keep per sample, rows in the packed row space.  Its own backward. */
+int mmae_scale_rows(int dtype, long rows, int W, const void* x, const float* row_scale, void* out, void* stream);
 /* ---- GELU of Mlp (DSI-MM/zorro_utils.py:141-143, MM/multimae_utils.py:148-150) -------------------------------------- */
 int mmae_gelu_fwd(int dtype, long n, const void* x, void* y, void* stream);
 int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, void* dx, void* stream);

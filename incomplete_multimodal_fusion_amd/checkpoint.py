@@ -59,6 +59,9 @@ def optimizer_state_dict(optimizer, model, balancer=None, balancer_lr_scale: flo
     if balancer_optimizer is not None:                     # PretrainStep's companion AdamW of the balancer group: its state
         bsd = balancer_optimizer.state_dict()              # is indexed from 0 there, from len(params) in the joint layout
         for i, st in bsd["state"].items():
+            st = dict(st)
+            if torch.is_tensor(st.get("step")):            # the companion keeps its step counts on the device (capturable);
+                st["step"] = st["step"].detach().float().cpu()   # the reference layout has CPU step tensors
             state[len(params) + int(i)] = st
     groups = [dict(common, lr_scale=g.get("lr_scale", 1.0), params=list(range(len(params)))),
               # the reference stores lr * lr_scale in a group (optim_factory.py:136-150 scales the group's lr when it is set)

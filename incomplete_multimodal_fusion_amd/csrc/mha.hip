@@ -479,6 +479,10 @@ extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, con
                                 empty_mode, 0, stream);
 }
 
+extern "C" long mmae_mha_bwd_ws_floats(int H, long q_rows_total) {
+    return (H <= 0 || q_rows_total <= 0) ? MMAE_ERR_ARG : 3L * H * q_rows_total;
+}
+
 extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk,
                             void* dv, long q_stride, long k_stride, long v_stride, long o_stride, long do_stride,

@@ -1247,6 +1247,48 @@ extern "C" int mmae_gelu_bwd(int dtype, long n, const void* x, const void* g, vo
     return MMAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------ per-row scale (DropPath)
+// out[r, :] = x[r, :] * scale[r]: stochastic depth (DSI-MM/zorro_utils.py:69-84) applied to a residual branch's output in the packed
+// row space -- scale[r] = floor(keep + u_sample(r)) / keep.  Runs only when a Block's drop_path rate is > 0 (reference default 0:
+// the bench path never launches it); one pass, 16 bytes per lane; its own backward (the same kernel on the gradient).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ out,
+                                                         long rows, int W, int sh) {
+    constexpr bool NT = V > 1;
+    const int per_row = W / V;
+    const long n = rows * per_row;
+    const long base = (long)blockIdx.x * (256 * EW_U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+        const long i = base + (long)u * 256;
+        if (i < n) {
+            long r; int c;
+            ew_row_col(i, per_row, sh, r, c);
+            float v[V];
+            ldv<T, V, NT>(x + r * W + (long)c * V, v);
+            const float s = scale[r];
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] *= s;
+            stv<T, V, NT>(out + r * W + (long)c * V, v);
+        }
+    }
+}
+extern "C" int mmae_scale_rows(int dtype, long rows, int W, const void* x, const float* row_scale, void* out, void* stream) {
+    if (!ok_dtype(dtype) || rows < 0 || W <= 0 || !x || !row_scale || !out) return MMAE_ERR_ARG;
+    if (rows == 0) return MMAE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int V = dtype == MMAE_BF16 ? 8 : 4;
+    const bool vec = (W % V) == 0 && al16(x) && al16(out);
+    const long per_row = vec ? W / V : W, n = rows * per_row;
+    if (ew_blocks(n) > 0x7fffffffL) return MMAE_ERR_ARG;
+    const int sh = log2_exact(per_row);
+#define GO(T, V) MMAE_LAUNCH((scale_rows_kernel<T, V>), dim3((unsigned)ew_blocks(n)), dim3(256), 0, st, (const T*)x, row_scale, (T*)out, rows, W, sh)
+    if (dtype == MMAE_BF16) { if (vec) GO(bf16, 8); else GO(bf16, 1); } else { if (vec) GO(float, 4); else GO(float, 1); }
+#undef GO
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ row gather / scatter
 // out[r, :] = src[idx[r], :]   (idx < 0 -> zeros).  W multiple of 4.  One wave per row.
 template <typename T>

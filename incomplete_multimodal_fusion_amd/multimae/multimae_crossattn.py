@@ -76,7 +76,6 @@ class MultiMAE(nn.Module):
         sibling pretraining/multimae/multimae_quadruplet.py model -- same encoder without the per-layer Block_Fusion, without
         mask_embedding and without the per-modality contrastive return tokens (see multimae_quadruplet.py here)."""
         super().__init__()
-        assert drop_path_rate == 0.0, "stochastic depth is 0 on this path (reference default, pretrain_mmae.py:108)"
         for adapter in input_adapters.values():
             adapter.init(dim_tokens=dim_tokens)
         self.input_adapters = nn.ModuleDict(input_adapters)
@@ -117,9 +116,10 @@ class MultiMAE(nn.Module):
                 Block_Fusion(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, norm_layer=norm_layer)
                 for _ in range(depth)])
             self.mask_embedding = nn.Parameter(torch.zeros(1, num_fusion_tokens, dim_tokens))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]      # stochastic depth decay rule (reference :132)
         self.blocks = nn.ModuleList([
-            Block(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, drop_path=0.0, norm_layer=norm_layer)
-            for _ in range(depth)])
+            Block(dim=dim_tokens, dim_head=dim_head, heads=heads, ff_mult=ff_mult, drop_path=dpr[i], norm_layer=norm_layer)
+            for i in range(depth)])
         self.norm = LayerNorm(dim_tokens)
 
         # behaviour switches of the native path (not part of the reference API)
@@ -318,10 +318,10 @@ class MultiMAE(nn.Module):
                                                out_dtype=T)                                 # (BN+BP, D)
             qkv = linear(z, [blk.attn.to_q.weight, blk.attn.to_kv.weight], side_wgrad=sw, once=True)
             a = ops.mha_self(qkv, Hh, dh, desc.enc_seg, blk.attn.scale)
-            o = linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True)
+            o = blk.drop_rows(linear(a, blk.attn.to_out.weight, side_wgrad=sw, once=True), B, (N, P))   # DropPath :238 (rate 0: identity)
             (xm, xf), y = ops.parts_add_ln([xm, xf], o, [0, BN], blk.norm2.gamma, None, blk.mlp[0].gamma, None,
                                            out_dtype=T)
-            f = ops.feedforward_geglu(y, blk.mlp[1].weight, blk.mlp[3].weight)                    # (BN+BP, D)
+            f = blk.drop_rows(ops.feedforward_geglu(y, blk.mlp[1].weight, blk.mlp[3].weight), B, (N, P))   # (BN+BP, D); DropPath :239
             if timed:
                 xm, xf, f = ops.layer_mark(lt, 1, xm, xf, f)
             dm, dm_off, df, df_off = f, 0, f, BN

@@ -88,10 +88,11 @@ class Block(nn.Module):          # multimae_utils.py:217-232
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        assert drop_path == 0.0 and drop == 0.0
+        assert drop == 0.0
+        from .zorro_utils import DropPath                                  # one implementation (multimae_utils.py:105-135 = zorro_utils.py:69-96)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()         # :224
         self.norm2 = norm_layer(dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
@@ -101,10 +102,11 @@ class Block(nn.Module):          # multimae_utils.py:217-232
         T = compute_dtype(self.attn.qkv.weight)
         (x,), y = ops.parts_add_ln([x], delta, [0 if delta is not None else -1], self.norm1.weight, self.norm1.bias,
                                    eps1=self.norm1.eps, out_dtype=T)
-        a = self.attn.forward_rows(y, B, N, seg, once)
+        dp = self.drop_path.rows if not isinstance(self.drop_path, nn.Identity) else (lambda t, *_: t)
+        a = dp(self.attn.forward_rows(y, B, N, seg, once), B, (N,))                                     # :230
         (x,), y = ops.parts_add_ln([x], a, [0], self.norm2.weight, self.norm2.bias, eps1=self.norm2.eps, out_dtype=T)
         h = linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, once=once)
-        f = linear(ops.gelu(h), self.mlp.fc2.weight, self.mlp.fc2.bias, once=once)
+        f = dp(linear(ops.gelu(h), self.mlp.fc2.weight, self.mlp.fc2.bias, once=once), B, (N,))        # :231
         return x, f
 
     def forward(self, x):

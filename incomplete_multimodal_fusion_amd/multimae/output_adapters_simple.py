@@ -25,7 +25,7 @@ class SpatialOutputAdapter(nn.Module):
                  use_task_queries: bool = True, task: Optional[str] = None, context_tasks: Optional[list] = None,
                  use_xattn: bool = True):
         super().__init__()
-        assert drop_rate == 0.0 and attn_drop_rate == 0.0 and drop_path_rate == 0.0
+        assert drop_rate == 0.0 and attn_drop_rate == 0.0
         self.num_channels, self.stride_level = num_channels, stride_level
         self.patch_size_full, self.image_size = pair(patch_size_full), pair(image_size)
         self.dim_tokens_enc, self.dim_tokens = dim_tokens_enc, dim_tokens
@@ -45,9 +45,11 @@ class SpatialOutputAdapter(nn.Module):
         else:
             self.pos_emb = nn.Parameter(trunc_normal_(torch.zeros(1, gh, gw, dim_tokens), std=0.02))
         if depth > 0:
+            dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]      # stochastic depth decay rule (reference :115)
             self.decoder_transformer = nn.Sequential(*[
-                Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, norm_layer=norm_layer)
-                for _ in range(depth)])
+                Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop_path=dpr[i],
+                      norm_layer=norm_layer)
+                for i in range(depth)])
         else:
             self.decoder_transformer = nn.Identity()
         self.dim_patch = num_channels * self.P_H * self.P_W

@@ -219,19 +219,68 @@ class Attention(nn.Module):      # zorro_utils.py:152-194
         return linear(a, self.to_out.weight).reshape(B, n, D)
 
 
+_DROP_PATH_DRAWS = None          # tests: a list of (B,) uniform draws consumed in call order instead of torch.rand
+
+
+def set_drop_path_draws(draws):
+    """Inject the uniform draws of the following training forward(s): one (B,) tensor per DropPath application, in the order the
+    reference's modules call torch.rand (per Block with rate > 0: attention branch, then feed-forward branch; encoder layers first,
+    then the decoders in domain order).  None restores torch.rand.  CPU and GPU generators differ, so parity tests inject."""
+    global _DROP_PATH_DRAWS
+    _DROP_PATH_DRAWS = None if draws is None else list(draws)
+
+
+class DropPath(nn.Module):       # zorro_utils.py:69-96 (= multimae_utils.py:105-135): stochastic depth per sample
+    """output = x / keep * floor(keep + u), u ~ U[0, 1) drawn per sample with shape (B, 1, ..., 1) in x's dtype (:79-83); identity
+    when drop_prob == 0 or in eval mode (:77-78).  On the packed row space `rows()` scales a residual branch's output row by row
+    (csrc/rowops.hip scale_rows_kernel)."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def active(self) -> bool:
+        return bool(self.drop_prob) and self.training
+
+    def draw(self, B: int, dtype, device) -> torch.Tensor:
+        if _DROP_PATH_DRAWS is not None:
+            return _DROP_PATH_DRAWS.pop(0).to(device=device).reshape(B)
+        return torch.rand((B, 1, 1), dtype=dtype, device=device).reshape(B)           # reference shape / dtype (:80-81)
+
+    def rows(self, x2d: torch.Tensor, B: int, counts) -> torch.Tensor:
+        """x2d: row blocks stacked as B * counts[0] rows, then B * counts[1] rows, ... (sample-major inside each block)."""
+        if not self.active():
+            return x2d
+        u = self.draw(B, x2d.dtype, x2d.device)
+        return ops.scale_rows(x2d, ops.drop_path_row_scale(u, self.drop_prob, counts))
+
+    def forward(self, x):
+        if not self.active():
+            return x
+        B, W = x.shape[0], x.shape[-1]
+        n = x.numel() // (B * W)
+        return self.rows(x.reshape(B * n, W).contiguous(), B, (n,)).reshape(x.shape)
+
+    def extra_repr(self) -> str:
+        return 'p={}'.format(self.drop_prob)
+
+
 class Block(nn.Module):          # zorro_utils.py:227-240
     def __init__(self, dim=768, dim_head=64, heads=8, ff_mult=4, drop_path=0., norm_layer=nn.LayerNorm):
         super().__init__()
-        assert drop_path == 0.0, "drop_path is 0 on this path (reference default, pretrain_mmae.py:108)"
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim=dim, dim_head=dim_head, heads=heads)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()          # :233
         self.norm2 = norm_layer(dim)
         self.mlp = FeedForward(dim=dim, mult=ff_mult)
 
+    def drop_rows(self, x2d, B, counts):
+        """DropPath of this block on a packed residual branch (identity at rate 0 / eval): :238-239."""
+        return self.drop_path.rows(x2d, B, counts) if isinstance(self.drop_path, DropPath) else x2d
+
     def forward(self, x, attn_mask, segments=None):
-        x = x.float() + self.attn(x, attn_mask=attn_mask, pre_gamma=self.norm1.gamma, segments=segments).float()
-        x = x + self.mlp(x, pre_gamma=self.norm2.gamma).float()
+        x = x.float() + self.drop_path(self.attn(x, attn_mask=attn_mask, pre_gamma=self.norm1.gamma, segments=segments)).float()
+        x = x + self.drop_path(self.mlp(x, pre_gamma=self.norm2.gamma)).float()
         return x
 
 

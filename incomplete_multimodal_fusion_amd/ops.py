@@ -512,7 +512,7 @@ class _MHA(torch.autograd.Function):
         gq = torch.empty_like(qt) if (qseg.covers_all and (not same or kseg.covers_all)) else torch.zeros_like(qt)
         gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
         # workspace: delta plus, for the bf16 kernels, the row constants of the key-stationary dK/dV kernel (3 planes of (H, rows))
-        delta = torch.empty((3,) + tuple(lse.shape), dtype=lse.dtype, device=lse.device)
+        delta = torch.empty(_lib.lib().mmae_mha_bwd_ws_floats(H, lse.shape[1]), dtype=lse.dtype, device=lse.device)
         es = qt.element_size()
         call("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
@@ -821,6 +821,39 @@ class _GELU(torch.autograd.Function):
 
 geglu = _GEGLU.apply
 gelu = _GELU.apply
+
+
+class _ScaleRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, row_scale):
+        x = _c(x)
+        assert x.dim() == 2 and row_scale.dtype == torch.float32 and row_scale.numel() == x.shape[0] and row_scale.is_contiguous()
+        out = torch.empty_like(x)
+        call("mmae_scale_rows", dt(x), x.shape[0], x.shape[1], ptr(x), ptr(row_scale), ptr(out), stream())
+        ctx.save_for_backward(row_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (row_scale,) = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(g)
+        call("mmae_scale_rows", dt(g), g.shape[0], g.shape[1], ptr(g), ptr(row_scale), ptr(gx), stream())
+        return gx, None
+
+
+def scale_rows(x, row_scale):
+    """x (rows, W) * row_scale (rows,) fp32, row by row: DropPath on a residual branch (zorro_utils.py:69-84)."""
+    return _ScaleRows.apply(x, row_scale)
+
+
+def drop_path_row_scale(u: torch.Tensor, drop_prob: float, counts):
+    """Per-row DropPath factors of the packed row space from one uniform draw per sample (zorro_utils.py:79-83:
+    random_tensor = floor(keep + u); output = x / keep * random_tensor).  counts: rows per sample of each row block, in the order
+    the blocks are stacked (e.g. (N, P): B*N modality rows then B*P fusion rows).  -> (sum(counts) * B,) fp32."""
+    keep = 1.0 - float(drop_prob)
+    s = torch.floor(keep + u.reshape(-1).float()) / keep
+    return torch.cat([s.repeat_interleave(int(c)) for c in counts]).contiguous()
 
 FF_CHUNKS = 1      # see _FeedForwardGEGLU: 2 was measured, no net gain
 

@@ -44,7 +44,8 @@ PRESETS = {'tiny': (192, 12, 3), 'small': (384, 12, 8), 'base': (768, 12, 8), 'l
 
 def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=None, patch_size: int = 16,
               input_size: int = 256, decoder_dim: int = 256, decoder_depth: int = 2, decoder_num_heads: int = 8,
-              dim_head: int = 64, domain_conf: Optional[dict] = None, fusion_blocks: bool = True):
+              dim_head: int = 64, domain_conf: Optional[dict] = None, fusion_blocks: bool = True, drop_path_rate: float = 0.0,
+              decoder_drop_path_rate: float = 0.0):
     """Adapters + model as get_model builds them (pretrain_mmae.py:193-246); `model` picks the size preset (the
     reference ignores --model and always builds the tiny factory, :239 -- SURVEY.md 0.5).  `domain_conf` defaults to the
     3-modality table, or to the 4-modality one when 'dnw' is among the domains.
@@ -68,7 +69,8 @@ def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=N
         d: SpatialOutputAdapter(num_channels=conf[d]['channels'], stride_level=conf[d]['stride_level'],
                                 patch_size_full=patch_size, dim_tokens=decoder_dim, depth=decoder_depth,
                                 num_heads=decoder_num_heads, use_task_queries=True, task=d,
-                                context_tasks=list(in_domains), use_xattn=True) for d in out_domains}
+                                context_tasks=list(in_domains), use_xattn=True, drop_path_rate=decoder_drop_path_rate)
+        for d in out_domains}
     input_adapters['fusion'] = FusionInputAdapter(num_channels=1, stride_level=1, patch_size_full=patch_size,
                                                   image_size=input_size)
     D, depth, heads = PRESETS[model]
@@ -87,7 +89,7 @@ def get_model(model: str = 'base', in_domains=('s1', 's2', 'dem'), out_domains=N
         cls = multimae_quadruplet.MultiMAE
     return cls(input_adapters=input_adapters, output_adapters=output_adapters, num_global_tokens=1,
                dim_tokens=D, depth=depth, dim_head=dim_head, heads=heads, ff_mult=4, num_fusion_tokens=P,
-               return_token_types=rtt, drop_path_rate=0.0)
+               return_token_types=rtt, drop_path_rate=drop_path_rate)     # pretrain_mmae.py:245 (args.drop_path, default 0 at :108)
 
 
 def make_loss_fns(out_domains=('s1', 's2', 'dem'), patch_size: int = 16, domain_conf: Optional[dict] = None):

@@ -605,6 +605,69 @@ def gen_quad():
     print("quad_tiny.npz:", len(bag), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+# Stochastic depth (drop_path_rate > 0, pretrain_mmae.py:108,245; DSI-MM/zorro_utils.py:69-96,233,238-239; decoder Blocks
+# MM/multimae_utils.py:224,230-231): one TRAINING forward + backward of the reference with a seeded global generator.  With explicit
+# task_masks the DropPath modules are the only consumers of that generator (torch.rand((B, 1, 1)) per application, attention branch
+# then feed-forward branch of every Block whose rate is > 0, encoder first, then the decoders in domain order), so the draws the
+# reference used are reproduced by re-seeding and drawing the same shapes in the same order; they go into the fixture.
+DROP_CFG = dict(dim_tokens=32, depth=3, dim_head=32, heads=2, image_size=64, patch_size=16,
+                decoder_dim=32, decoder_depth=2, decoder_heads=1, drop_path_rate=0.5, decoder_drop_path_rate=0.4)
+
+
+def gen_droppath(ref):
+    torch.manual_seed(11)
+    model = ref_loader.build_reference_model(ref, channels=CHANNELS, **DROP_CFG)
+    gen = torch.Generator().manual_seed(123)
+    rand_init_(model, gen, scale=0.3)
+    with torch.no_grad():
+        model.mask_embedding.add_(0.05 * torch.randn(model.mask_embedding.shape, generator=gen))
+    model.train()
+    B, P = 6, 16
+    x = {d: torch.randn(B, c, 64, 64, generator=gen) for d, c in CHANNELS}
+    keep = {"s1": [0, 3, 5, 6, 9, 10, 12, 15, 2, 7], "s2": [1, 2, 4, 8, 11, 13, 14, 0], "dem": [5, 6, 7, 9, 12, 3]}
+    masks = {}
+    for d, idx in keep.items():
+        row = torch.ones(P, dtype=torch.long); row[torch.tensor(idx, dtype=torch.long)] = 0
+        masks[d] = row[None].repeat(B, 1)
+    N = int(sum((m[0] == 0).sum() for m in masks.values()))
+    SEED = 2024
+    # the draws, in consumption order: encoder layers with rate > 0 (linspace(0, rate, depth): layer 0 has none), two each; then per
+    # decoder (s1, s2, dem) its Blocks with rate > 0, two each
+    enc_rates = [v.item() for v in torch.linspace(0, DROP_CFG["drop_path_rate"], DROP_CFG["depth"])]
+    dec_rates = [v.item() for v in torch.linspace(0, DROP_CFG["decoder_drop_path_rate"], DROP_CFG["decoder_depth"])]
+    n_draws = 2 * sum(1 for r in enc_rates if r > 0) + 3 * 2 * sum(1 for r in dec_rates if r > 0)
+    torch.manual_seed(SEED)
+    draws = torch.stack([torch.rand((B, 1, 1)).reshape(B) for _ in range(n_draws)])
+    state_after = torch.get_rng_state()
+    torch.manual_seed(SEED)
+    model.zero_grad()
+    out = model(x, task_masks=masks, num_encoded_tokens=N)
+    assert torch.equal(torch.get_rng_state(), state_after), "the forward consumed a different number of draws"
+    task_losses, loss_contra, loss = harness_losses(ref, out, x, masks)
+    loss.backward()
+    # both outcomes must occur for the fixture to pin anything: some (sample, branch) pairs dropped, some kept
+    rates = [r for r in enc_rates if r > 0 for _ in range(2)] + [r for _ in range(3) for r in dec_rates if r > 0 for _ in range(2)]
+    kept = torch.stack([torch.floor((1 - r) + u) for r, u in zip(rates, draws)])
+    assert 0 < int(kept.sum()) < kept.numel()
+    preds, tm, pooled, ori, fus, s1_t, s2_t, dem_t = out
+    bag = Bag()
+    bag["config"] = np.array(json.dumps(dict(DROP_CFG, channels=CHANNELS, B=B, N=N)))
+    for k, v in model.state_dict().items():
+        bag["state/" + k] = npy(v)
+    for d in x:
+        bag["x/" + d] = npy(x[d]); bag["mask/" + d] = npy(masks[d]); bag["pred/" + d] = npy(preds[d])
+        bag["task_loss/" + d] = npy(task_losses[d])
+    bag["draws"] = npy(draws)
+    bag.put("out", pooled=pooled, ori_tokens=ori, fusion_tokens=fus, ret_s1=s1_t, ret_s2=s2_t, ret_dem=dem_t,
+            loss_contra=loss_contra, loss=loss)
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            bag["grad/" + n] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, "droppath.npz"), **bag)
+    print("droppath.npz:", len(bag), "arrays;", int(kept.numel() - kept.sum()), "of", kept.numel(), "(sample, branch) pairs dropped")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # single-threaded reductions: the fixtures regenerate byte for byte
@@ -615,5 +678,6 @@ if __name__ == "__main__":
     gen_downstream()
     gen_aux()
     gen_quad()
+    gen_droppath(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -70,7 +70,7 @@ def load():
 
 def build_reference_model(ref, *, dim_tokens, depth, dim_head, heads, image_size, patch_size=16,
                           channels=(("s1", 1), ("s2", 3), ("dem", 1)),
-                          decoder_dim=256, decoder_depth=2, decoder_heads=8):
+                          decoder_dim=256, decoder_depth=2, decoder_heads=8, drop_path_rate=0.0, decoder_drop_path_rate=0.0):
     """Builds reference adapters + MultiMAE the way pretraining/pretrain_mmae.py:193-246 does,
     with free sizes (the class takes arbitrary dims; the factories only fix presets)."""
     from functools import partial
@@ -85,7 +85,7 @@ def build_reference_model(ref, *, dim_tokens, depth, dim_head, heads, image_size
         d: ref.oa.SpatialOutputAdapter(num_channels=c, stride_level=1, patch_size_full=patch_size,
                                        dim_tokens=decoder_dim, depth=decoder_depth,
                                        num_heads=decoder_heads, use_task_queries=True, task=d,
-                                       context_tasks=list(in_domains), use_xattn=True)
+                                       context_tasks=list(in_domains), use_xattn=True, drop_path_rate=decoder_drop_path_rate)
         for d, c in channels
     }
     input_adapters["fusion"] = ref.ia.FusionInputAdapter(num_channels=1, stride_level=1,
@@ -97,7 +97,7 @@ def build_reference_model(ref, *, dim_tokens, depth, dim_head, heads, image_size
                             dim_head=dim_head, heads=heads, ff_mult=4,
                             num_fusion_tokens=num_patches,
                             return_token_types=(T.S1, T.S2, T.DEM, T.FUSION),
-                            drop_path_rate=0.0, norm_layer=ref.zu.LayerNorm)
+                            drop_path_rate=drop_path_rate, norm_layer=ref.zu.LayerNorm)
     return model
 
 

@@ -124,3 +124,71 @@ def test_flat_engine_optimizer_round_trip(tmp_path, g_e2e):
     ref_t.step()                                                             # same gradients again on the torch side
     for (n, a), (_, b) in zip(model_g.named_parameters(), model_t.named_parameters()):
         assert torch.allclose(a, b, rtol=0, atol=3e-6), n
+
+
+class _FakeFlat:
+    """The attributes of engine.FlatAdamW that checkpoint.optimizer_state_dict / load_optimizer_state_dict touch, on the CPU
+    (the real engine needs the GPU: tests/test_gpu_engine.py runs the same round trip with it)."""
+
+    def __init__(self, params, lr=1e-3):
+        self.params = [p for p in params if p.requires_grad]
+        self.offsets, o = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = o; o += p.numel()
+        self.exp_avg = torch.randn(o); self.exp_avg_sq = torch.rand(o)
+        self._pstep = {id(p): 3 for p in self.params}
+        self.param_groups = [{"lr": lr, "weight_decay": 0.05, "lr_scale": 1.0}]
+        self.betas, self.eps, self.steps = (0.9, 0.95), 1e-8, 3
+
+    def skipped_steps(self):
+        return 0
+
+    def set_param_steps(self, steps):
+        self._pstep = dict(steps); self.steps = max(steps.values()) if steps else 0
+
+    def refresh_shadow(self):
+        pass
+
+
+def test_balancer_group_of_the_flat_engine_checkpoint_layout(tmp_path, g_e2e):
+    """the loss balancer's optimizer group next to a flat engine.  The companion AdamW's state is indexed from 0 there
+    and from len(model params) in the reference's joint two-group layout (len(params) + i on save, i - n0 on load), and group 1
+    records lr * lr_scale as the reference trainer's optimizer does (utils/optim_factory.py:136-150, pretrain_mmae.py:439-445)."""
+    from incomplete_multimodal_fusion_amd import checkpoint as C
+    from incomplete_multimodal_fusion_amd.pretrain import UncertaintyWeightingStrategy, create_optimizer
+    model = _tiny(g_e2e)
+    bal = UncertaintyWeightingStrategy(["s1", "s2", "dem"])
+    eng = _FakeFlat(model.parameters(), lr=1e-3)
+    comp = torch.optim.AdamW(bal.parameters(), lr=2e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    for _ in range(2):
+        bal.log_vars.grad = torch.tensor([0.5, -1.0, 2.0])
+        comp.step()
+    sd = C.optimizer_state_dict(eng, model, bal, balancer_lr_scale=2.0, balancer_optimizer=comp)
+    n = len(eng.params)
+    assert [len(g["params"]) for g in sd["param_groups"]] == [n, 1] and sd["param_groups"][1]["params"] == [n]
+    assert sd["param_groups"][1]["lr"] == pytest.approx(2e-3) and sd["param_groups"][1]["lr_scale"] == 2.0
+    assert sd["param_groups"][0]["lr"] == pytest.approx(1e-3)
+    assert float(sd["state"][n]["step"]) == 2.0 and torch.equal(sd["state"][n]["exp_avg"], comp.state[bal.log_vars]["exp_avg"])
+    # (1) the file loads into ONE optimizer built the reference way (torch's own checks: group sizes, shapes)
+    C.save_model(str(tmp_path), 2, model, eng, loss_balancer=bal, balancer_lr_scale=2.0, balancer_optimizer=comp)
+    model_t, bal_t = _tiny(g_e2e), UncertaintyWeightingStrategy(["s1", "s2", "dem"])
+    ref = create_optimizer(model_t, bal_t, lr=9.0, balancer_lr_scale=2.0)
+    assert C.auto_load_model(str(tmp_path), model_t, ref, loss_balancer=bal_t) == 3
+    assert torch.equal(bal_t.log_vars, bal.log_vars)
+    st = ref.state_dict()["state"]
+    assert torch.equal(st[n]["exp_avg_sq"], comp.state[bal.log_vars]["exp_avg_sq"]) and float(st[n]["step"]) == 2.0
+    assert ref.param_groups[1]["lr"] == pytest.approx(2e-3)
+    # (2) ... and back into an engine + companion pair: the companion receives group 1, re-indexed from 0
+    model_f, bal_f = _tiny(g_e2e), UncertaintyWeightingStrategy(["s1", "s2", "dem"])
+    eng_f = _FakeFlat(model_f.parameters(), lr=7.0)
+    comp_f = torch.optim.AdamW(bal_f.parameters(), lr=7.0)
+    assert C.auto_load_model(str(tmp_path), model_f, eng_f, loss_balancer=bal_f, balancer_optimizer=comp_f) == 3
+    assert torch.equal(comp_f.state[bal_f.log_vars]["exp_avg"], comp.state[bal.log_vars]["exp_avg"])
+    assert float(comp_f.state[bal_f.log_vars]["step"]) == 2.0
+    assert torch.equal(eng_f.exp_avg, eng.exp_avg) and eng_f.param_groups[0]["lr"] == pytest.approx(1e-3)
+    # one more identical step on both companions: identical log_vars (state AND hyper-parameters arrived)
+    for b_, c_ in ((bal, comp), (bal_f, comp_f)):
+        for g_ in c_.param_groups:
+            g_["lr"] = 2e-3; g_["betas"] = (0.9, 0.95); g_["weight_decay"] = 0.05
+        b_.log_vars.grad = torch.tensor([1.0, 1.0, -1.0]); c_.step()
+    assert torch.allclose(bal_f.log_vars, bal.log_vars, rtol=0, atol=1e-7)

@@ -274,3 +274,64 @@ def test_pretrain_step_clip_and_finite_guard():
     assert torch.equal(opt.master, before) and torch.isfinite(opt.master).all()
     step(x)
     assert not opt.last_step_skipped() and not torch.equal(opt.master, before)
+
+
+def test_loss_balancer_companion_follows_the_engine(tmp_path):
+    """a trainable loss balancer (UncertaintyWeightingStrategy.log_vars) next to the flat engine is optimised by a
+    companion AdamW inside PretrainStep.  (1) Its trajectory equals the second group of ONE torch AdamW built the reference way
+    (create_optimizer({'model', 'balancer'}), utils/optim_factory.py:136-150).  (2) A step the engine's device-side control skips
+    (non-finite gradient norm: GradScaler's guard in the reference, native_scaler.py:24-37) skips log_vars, their moments and
+    their step count too -- without it one NaN loss left log_vars NaN for good.  (3) save_model / auto_load_model round trip."""
+    from incomplete_multimodal_fusion_amd import checkpoint as C
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep, UncertaintyWeightingStrategy, create_optimizer, get_model
+    torch.manual_seed(3)
+    base = get_model("small", input_size=128, decoder_dim=64, decoder_depth=1, decoder_num_heads=2)
+    base.depth = 2; base.blocks = base.blocks[:2]; base.fus_blocks = base.fus_blocks[:2]
+    B, P, N, doms = 8, 64, 96, ["s1", "s2", "dem"]
+    x = {"s1": torch.randn(B, 1, 128, 128, device=DEV), "s2": torch.randn(B, 3, 128, 128, device=DEV),
+         "dem": torch.randn(B, 1, 128, 128, device=DEV)}
+    masks = {}
+    for d, k in (("s1", 40), ("s2", 30), ("dem", 26)):
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1).to(DEV)
+    lr, scale = 1e-3, 2.0
+    model_r, bal_r = copy.deepcopy(base).to(DEV).train(), UncertaintyWeightingStrategy(doms).to(DEV)
+    opt_r = create_optimizer(model_r, bal_r, lr=lr, balancer_lr_scale=scale)
+    opt_r.param_groups[1]["lr"] = lr * scale                       # what the driver's per-step lr assignment does (pretrain_mmae.py:439-445)
+    step_r = PretrainStep(model_r, opt_r, N, loss_balancer=bal_r)
+    model_e, bal_e = copy.deepcopy(base).to(DEV).train(), UncertaintyWeightingStrategy(doms).to(DEV)
+    opt_e = FlatAdamW(model_e.parameters(), lr=lr, betas=(0.9, 0.95), weight_decay=0.05, exclude=model_e.never_used_parameters())
+    step_e = PretrainStep(model_e, opt_e, N, loss_balancer=bal_e, balancer_lr_scale=scale, check_finite=True)
+    assert step_e.balancer_opt is not None and step_r.balancer_opt is None
+    for it in range(3):
+        step_r(x, task_masks=masks); step_e(x, task_masks=masks)
+        assert float((bal_e.log_vars - bal_r.log_vars).abs().max()) < 2e-5, (it, bal_e.log_vars, bal_r.log_vars)
+    assert float(bal_e.log_vars.abs().max()) > 1e-3                # they did move
+    # (2) a poisoned batch: NaN loss -> the engine skips the model update; log_vars and their Adam state must sit it out too
+    bad = dict(x); bad["s1"] = x["s1"].clone(); bad["s1"][0, 0, 0, 0] = float("nan")
+    lv0 = bal_e.log_vars.detach().clone()
+    st0 = {k: v.detach().clone() for k, v in step_e.balancer_opt.state[bal_e.log_vars].items() if torch.is_tensor(v)}
+    w0 = opt_e.master.clone()
+    out = step_e(bad, task_masks=masks)
+    assert not torch.isfinite(out["loss"]) and opt_e.last_step_skipped()
+    assert torch.equal(opt_e.master, w0) and torch.equal(bal_e.log_vars, lv0) and torch.isfinite(bal_e.log_vars).all()
+    for k, v in step_e.balancer_opt.state[bal_e.log_vars].items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, st0[k]), k                        # moments AND step count
+    step_r(x, task_masks=masks); step_e(x, task_masks=masks)        # the reference-way run never saw the poisoned batch
+    assert float((bal_e.log_vars - bal_r.log_vars).abs().max()) < 5e-5
+    # (3) checkpoint round trip through the reference's joint two-group layout
+    C.save_model(str(tmp_path), 1, model_e, opt_e, loss_balancer=bal_e, balancer_lr_scale=scale, balancer_optimizer=step_e.balancer_opt)
+    model_f, bal_f = copy.deepcopy(base).to(DEV).train(), UncertaintyWeightingStrategy(doms).to(DEV)
+    opt_f = FlatAdamW(model_f.parameters(), lr=9.0, betas=(0.9, 0.95), weight_decay=0.0, exclude=model_f.never_used_parameters())
+    step_f = PretrainStep(model_f, opt_f, N, loss_balancer=bal_f, balancer_lr_scale=scale, check_finite=True)
+    assert C.auto_load_model(str(tmp_path), model_f, opt_f, loss_balancer=bal_f, balancer_optimizer=step_f.balancer_opt,
+                             map_location="cuda") == 2
+    assert torch.equal(bal_f.log_vars, bal_e.log_vars) and opt_f.param_groups[0]["lr"] == lr
+    step_e(x, task_masks=masks); step_f(x, task_masks=masks)
+    assert float((bal_f.log_vars - bal_e.log_vars).abs().max()) < 1e-6
+    model_t, bal_t = copy.deepcopy(base).to(DEV).train(), UncertaintyWeightingStrategy(doms).to(DEV)
+    opt_t = create_optimizer(model_t, bal_t, lr=9.0, balancer_lr_scale=scale)
+    assert C.auto_load_model(str(tmp_path), model_t, opt_t, loss_balancer=bal_t, map_location="cuda") == 2
+    assert opt_t.param_groups[1]["lr"] == pytest.approx(lr * scale) and opt_t.param_groups[1]["lr_scale"] == scale
