@@ -1,0 +1,362 @@
+// Dense projections C[M, N] = A[M, K] . W[N, K]^T (bf16 in / bf16 out, fp32 accumulate) as a hand-written gfx950 kernel -- the forward and
+// input-gradient GEMMs of the encoder (reference: the nn.Linear calls of DSI-MM/zorro_utils.py:181-182,192 (to_q / to_kv / to_out) and
+// :125-127 (FeedForward), autograd's dX = dY . W for the same layers) -- with an optional GEGLU epilogue (:115-118) for FeedForward[1].
+//
+// Structure (cdna_hip_programming.md section 5, "The 256^2 8-phase template", written from that description; go / no-go history and the
+// diagnostic builds: tools/probes/gemm8p_probe.hip): 256 x 256 x 64 tiles, 8 waves (2 along M x 4 along N, 128 x 64 of C per wave in 128
+// accumulator registers), v_mfma_f32_16x16x32_bf16; operands by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction) into two 64 KB tile
+// buffers, swizzled on the SOURCE address + the same XOR on the b128 fragment reads (conflict-free); 4 phases per K-tile (one 64 x 32
+// quadrant of the wave's tile x K 64 = 16 MFMAs), each = { ds_read the quadrant's fragments, ONE staging step (2 DMA per lane), [counted
+// s_waitcnt vmcnt(N), never 0 in the loop], raw s_barrier, MFMAs under s_setprio(1), raw s_barrier }; waves 4..7 run one barrier behind
+// waves 0..3, so on every SIMD one wave issues MFMAs while its partner reads LDS and issues DMA.
+// PERSISTENT: 256 workgroups (one per CU: 128 KB of LDS each) walk the tiles in an XCD-aware order (the 32 workgroups of an XCD hold a few
+// A row-panels x up to 8 W panels at a time); the staging schedule runs on into the next tile's K-tiles 0 / 1, and the epilogue ROLLS by
+// halves: rows 0..63 of a wave's tile are final after phase 1 of the last K-tile and are stored in its phases 2 / 3, rows 64..127 in phases
+// 0 / 1 of the next tile's first K-tile.  The product is oriented so that an MFMA column is an output column and the W tile sits in LDS in a
+// permuted row order (free: an LDS-DMA lane fetches any source row): lane j of a 16-lane group then holds 4 CONSECUTIVE columns of one C
+// row and the group writes one whole 128-byte line -- every store instruction = 4 complete lines -- with the nontemporal policy (C is
+// written once and read by a later kernel: streaming lines must not evict the A / W panels from L2; worth +18 % on the FF1 shape).
+// Measured in isolation (M 163 840, N 4096, K 768, uniform random operands): 1303 TFLOP/s against 1206-1228 for the tuned library GEMM.
+//
+// Staging granule = a quarter tile (64 rows x 64 k = 8 KB = one DMA per lane), two per phase.  Liveness (K-tile t lives in buffer t & 1):
+//     A-lo quarters (rows 0..63 of both 128-row halves): read in phase 0           -> restaged in phase 2 with K-tile t+2
+//     W half 0 / half 1                                : read in phases 0, 1        -> restaged in phase 3 (t+2) / phase 0 of t+1 (t+2)
+//     A-hi quarters                                    : read in phase 2            -> restaged in phase 1 of t+1 (t+2)
+//   a region is restaged >= 2 phases after its last read, every read is >= 1 phase after the counted wait that retires its DMA, and 3-4
+//   staging steps stay in flight across the barriers.  vmcnt counts DMA loads AND stores in issue order: the counts below include the rolling
+//   epilogue's stores (too low a count only waits longer, too high a count would read a tile early).
+#include "common.hpp"
+#include "mmae_hip.h"
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define LDS_AS __attribute__((address_space(3)))
+#define GM_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define GM_STORE_AUX 2            // nt
+
+namespace {
+
+__device__ __forceinline__ unsigned gm_pack2(float lo, float hi) {          // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// exact-erf GELU as x * Phi(x), Phi from one exp2 + one rcp (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7): the formula of rowops.hip's
+// geglu_fwd_kernel, so the fused and the separate path round identically
+__device__ __forceinline__ float gm_gelu(float x) {
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_erfc = 0.5f * poly * t * e;
+    return x * (x >= 0.f ? 1.f - half_erfc : half_erfc);
+}
+
+struct GemmArgs {
+    const bf16* A; const bf16* W; bf16* C; bf16* G;      // G: GEGLU product (EPI 1), else unused
+    int M, N, K;                                         // EPI 1: N = F output pairs (W has 2 F rows: val rows [0, F), gate rows [F, 2 F))
+    int lda, ldw, ldc, ldg;                              // elements
+    int ntm, ntn;                                        // tiles: ceil(M / 256) x N / 256 (EPI 1: F / 128)
+};
+
+struct TileXY { int tm, tn; };
+// Tiles of one XCD group x (= workgroup % 8: the workgroups that share an L2 under round-robin placement -- speed only): M-panels
+// [m0, m1), walked in chunks of up to 8 N-tiles (a chunk's W panels stay L2-resident while the A panels stream); local tile index i.
+__device__ __forceinline__ TileXY tile_of(int x, int i, int ntm, int ntn) {
+    const int q = ntm / 8, r = ntm % 8;
+    const int m0 = x * q + (x < r ? x : r), rows = q + (x < r ? 1 : 0);
+    const int GN = ntn < 8 ? ntn : 8, nc = ntn / GN, rem = ntn - nc * GN, full = nc * rows * GN;
+    TileXY t;
+    if (i < full) { const int c = i / (rows * GN), rr = i - c * rows * GN; t.tm = m0 + rr / GN; t.tn = c * GN + rr % GN; }
+    else { const int rr = i - full; t.tm = m0 + rr / rem; t.tn = nc * GN + rr % rem; }
+    return t;
+}
+__device__ __forceinline__ int tiles_of_xcd(int x, int ntm, int ntn) { return (ntm / 8 + (x < ntm % 8 ? 1 : 0)) * ntn; }
+
+// Buffer descriptors are rebuilt at every use from (kernel-argument pointer, record count): a descriptor held live costs 4 SGPRs, and the
+// kernel addresses six of them (A, W, C, G of the current tile, A / W of the next, C / G of the previous one) -- kept whole they spill.
+struct Ctx {
+    unsigned nA, nW;                     // record counts (bytes) of A / W; 0 for a tile that does not exist (the DMA then zero-fills dead LDS)
+    int sA, sW;                          // scalar byte offsets of this wave's first piece row in A / W
+};
+struct Out { unsigned nC, nG; int c, g; };     // record counts of C / G (0: stores dropped) and the wave's tile origin (bytes) in them
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gm_rsrc(const void* p, unsigned n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+struct Lane {
+    char* lds;
+    int voffA, voffW;                    // per-lane DMA source offsets (8 rows x 128 B piece)
+    int rdA[2], rdW[2];                  // fragment read offsets, k-step 0 / 1
+    int voffC, voffG;                    // per-lane byte offsets inside C / G
+    int lda2, ldw2, ldc2, ldg2;          // bytes per row
+    int wgrp;                            // W rows per 64-row LDS group step in the source (EPI 0: 64, EPI 1: 32), in bytes of W: wgrp * ldw2
+    int gate_off;                        // EPI 1: byte offset of the gate columns inside a row of C (F * 2)
+    const bf16* A; const bf16* W; bf16* C; bf16* G;
+};
+
+__device__ __forceinline__ void gm_dma(const void* base, unsigned nrec, int voff, int soff, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(gm_rsrc(base, nrec), (LDS_AS void*)dst, 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
+}
+// A quarter pair hi (0: rows 0..63 of both 128-row halves, 1: rows 64..127) of K-tile kt into buffer buf
+__device__ __forceinline__ void stageA(const Lane& L, const Ctx& c, int kt, int buf, int hi, int wave) {
+    const int row = 64 * hi + 8 * wave;
+    gm_dma(L.A, c.nA, L.voffA, c.sA + 64 * hi * L.lda2 + kt * 128, L.lds + buf * 65536 + row * 128);
+    gm_dma(L.A, c.nA, L.voffA, c.sA + (128 + 64 * hi) * L.lda2 + kt * 128, L.lds + buf * 65536 + (128 + row) * 128);
+}
+// W half (0: LDS rows 0..127 = the 64-row groups of waves wc 0, 1; 1: rows 128..255) of K-tile kt into buffer buf
+__device__ __forceinline__ void stageW(const Lane& L, const Ctx& c, int kt, int buf, int half, int wave) {
+    const int row = 128 * half + 8 * wave;
+    gm_dma(L.W, c.nW, L.voffW, c.sW + 2 * half * L.wgrp + kt * 128, L.lds + buf * 65536 + 32768 + row * 128);
+    gm_dma(L.W, c.nW, L.voffW, c.sW + (2 * half + 1) * L.wgrp + kt * 128, L.lds + buf * 65536 + 32768 + (row + 64) * 128);
+}
+struct Frags {
+    bf16x8 a[4][2];                      // A fragments of the current 64-row group (a operand: row = m)
+    bf16x8 wlo[2][2], whi[2][2];         // W fragments, n-tiles 0, 1 / 2, 3 (b operand: column j)
+};
+__device__ __forceinline__ bf16x8 lds8(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+template <int Q>
+__device__ __forceinline__ void load_frags(const Lane& L, int buf, Frags& f) {
+    const char* base = L.lds + buf * 65536;
+    if (Q == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) f.wlo[ni][ks] = lds8(base + L.rdW[ks] + ni * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (Q == 1) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) f.whi[ni][ks] = lds8(base + L.rdW[ks] + (2 + ni) * 2048);
+    }
+    if (Q == 0 || Q == 2) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) f.a[mi][ks] = lds8(base + L.rdA[ks] + ((Q == 2 ? 4 : 0) + mi) * 2048);
+    }
+}
+// quadrant Q = (m group, n pair) (0,0) (0,1) (1,1) (1,0); acc[mi][ni]: rows 16 mi + 4 g + reg of the wave's tile, MFMA column j
+template <int Q, bool FIRST>
+__device__ __forceinline__ void mfma_phase(const Frags& f, f32x4 (&acc)[8][4]) {
+    constexpr int qa = Q >= 2, qb = (Q == 1 || Q == 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const f32x4 cin = (FIRST && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 * qa + mi][2 * qb + ni];
+                acc[4 * qa + mi][2 * qb + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi][ks], qb ? f.whi[ni][ks] : f.wlo[ni][ks], cin, 0, 0, 0);
+            }
+}
+// Rows 64 QA + 32 PART .. + 32 of the wave's tile.
+//   EPI 0: MFMA column j of n-tile ni is C column 4 j + ni of the wave's 64: 8 stores of 8 bytes per lane, each = 4 whole 128-byte lines.
+//   EPI 1: n-tiles 0, 1 are val columns 2 j, 2 j + 1 of the wave's 32, n-tiles 2, 3 the gate columns of the same pair: per row one 4-byte
+//          store each for val, gate (into h = C) and gelu(gate) * val (into G); the 16 lanes of a group write 64 contiguous bytes.
+template <int EPI, int QA, int PART>
+__device__ __forceinline__ void store_half(const f32x4 (&acc)[8][4], const Lane& L, const Out& o) {
+    const __amdgpu_buffer_rsrc_t rsC = gm_rsrc(L.C, o.nC), rsG = gm_rsrc(EPI == 0 ? L.C : L.G, o.nG);
+    const int corigin = o.c, gorigin = o.g;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+        const int mi = 4 * QA + 2 * PART + m2;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (EPI == 0) {
+                u32x2 v;
+                v[0] = gm_pack2(acc[mi][0][reg], acc[mi][1][reg]); v[1] = gm_pack2(acc[mi][2][reg], acc[mi][3][reg]);
+                __builtin_amdgcn_raw_buffer_store_b64(v, rsC, L.voffC, __builtin_amdgcn_readfirstlane(corigin + (16 * mi + reg) * L.ldc2), GM_STORE_AUX);
+            } else {
+                // h keeps the values the backward reads (GEGLU' needs val and gate), rounded to bf16 exactly as a separate GEMM would
+                // round them; the product is formed from those rounded values (= what geglu_fwd_kernel computes from h)
+                const unsigned hv = gm_pack2(acc[mi][0][reg], acc[mi][1][reg]), hg = gm_pack2(acc[mi][2][reg], acc[mi][3][reg]);
+                const bf16x2 bv = __builtin_bit_cast(bf16x2, hv), bg = __builtin_bit_cast(bf16x2, hg);
+                const unsigned pr = gm_pack2(gm_gelu((float)bg[0]) * (float)bv[0], gm_gelu((float)bg[1]) * (float)bv[1]);
+                const int so = __builtin_amdgcn_readfirstlane(corigin + (16 * mi + reg) * L.ldc2);
+                __builtin_amdgcn_raw_buffer_store_b32(hv, rsC, L.voffC, so, GM_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(hg, rsC, L.voffC, so + L.gate_off, GM_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(pr, rsG, L.voffG, __builtin_amdgcn_readfirstlane(gorigin + (16 * mi + reg) * L.ldg2), GM_STORE_AUX);
+            }
+        }
+    }
+}
+#define GM_PHASE_TAIL(Q, FIRST)                                            \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_barrier();                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_setprio(1);                                         \
+    mfma_phase<Q, FIRST>(f, acc);                                          \
+    __builtin_amdgcn_s_setprio(0);                                         \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_barrier();                                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+constexpr int vmc(int n) { return n > 63 ? 63 : n; }       // the vmcnt field has 6 bits; a smaller count only waits for more
+
+// One K-tile.  KIND 0: steady; 1: FIRST K-tile of an output tile (chains start from zero; rows 64..127 of the PREVIOUS tile are stored in
+// phases 0 / 1); 2: the K-tile after it; 3: LAST K-tile (rows 0..63 of this tile stored in phases 2 / 3).  (c1, kt1) / (c2, kt2): where the
+// K-tiles "t+1" / "t+2" live (they may belong to the next output tile).  SPP = stores per storing phase (after the phase's DMA and wait).
+template <int EPI, int KIND>
+__device__ __forceinline__ void ktile(const Lane& L, const Ctx& c1, int kt1, const Ctx& c2, int kt2, int b, int wave, Frags& f, f32x4 (&acc)[8][4],
+                                      const Out& prev, const Out& cur) {
+    constexpr bool FIRST = KIND == 1, LAST = KIND == 3;
+    constexpr int SPP = EPI == 0 ? 8 : 24;
+    load_frags<0>(L, b, f);
+    stageW(L, c1, kt1, b ^ 1, 1, wave);
+    if (FIRST) store_half<EPI, 1, 0>(acc, L, prev);
+    GM_PHASE_TAIL(0, FIRST)
+    load_frags<1>(L, b, f);
+    stageA(L, c1, kt1, b ^ 1, 1, wave);
+    // A-hi of THIS K-tile (issued 4 staging steps ago) has landed
+    if (FIRST) GM_VMCNT(vmc(8 + 3 * SPP)); else if (KIND == 2) GM_VMCNT(vmc(8 + SPP)); else GM_VMCNT(8);
+    if (FIRST) store_half<EPI, 1, 1>(acc, L, prev);
+    GM_PHASE_TAIL(1, FIRST)
+    load_frags<2>(L, b, f);
+    stageA(L, c2, kt2, b, 0, wave);
+    if (LAST) store_half<EPI, 0, 0>(acc, L, cur);
+    GM_PHASE_TAIL(2, FIRST)
+    stageW(L, c2, kt2, b, 0, wave);
+    // A-lo, W half 0, W half 1 of the next K-tile have landed
+    if (LAST) GM_VMCNT(vmc(6 + SPP)); else if (FIRST) GM_VMCNT(vmc(6 + 2 * SPP)); else GM_VMCNT(6);
+    if (LAST) store_half<EPI, 0, 1>(acc, L, cur);
+    GM_PHASE_TAIL(3, FIRST)
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int x = blockIdx.x & 7, jw = blockIdx.x >> 3, nper = gridDim.x >> 3;            // grid = 8 * nper workgroups
+    const int txcd = tiles_of_xcd(x, p.ntm, p.ntn);
+    const int ntile = (txcd - jw + nper - 1) / nper;                                       // local indices jw, jw + nper, ...
+    if (ntile <= 0) return;
+    const int wrows = EPI == 0 ? p.N : 2 * p.N;
+    const unsigned szA = (unsigned)(((long)(p.M - 1) * p.lda + p.K) * 2), szW = (unsigned)(((long)(wrows - 1) * p.ldw + p.K) * 2);
+    const unsigned szC = (unsigned)(((long)(p.M - 1) * p.ldc + wrows) * 2), szG = EPI == 0 ? 0u : (unsigned)(((long)(p.M - 1) * p.ldg + p.N) * 2);
+    Lane L;
+    L.lds = lds;
+    L.lda2 = p.lda * 2; L.ldw2 = p.ldw * 2; L.ldc2 = p.ldc * 2; L.ldg2 = p.ldg * 2;
+    L.wgrp = (EPI == 0 ? 64 : 32) * L.ldw2;
+    L.gate_off = p.N * 2;
+    L.A = p.A; L.W = p.W; L.C = p.C; L.G = p.G;
+    {
+        const int pr = lane >> 3, ch = lane & 7, j = lane & 15, g = lane >> 4;
+        L.voffA = pr * L.lda2 + 16 * (ch ^ pr);
+        L.voffW = (EPI == 0 ? 4 : 2) * pr * L.ldw2 + 16 * (ch ^ pr);       // the 8 LDS rows of a piece are MFMA columns j0 .. j0 + 7 of one n-tile
+        const int ra = (128 * wr + j) * 128 + 16 * (g ^ (j & 7));
+        const int rw = 32768 + (64 * wc + j) * 128 + 16 * (g ^ (j & 7));
+        L.rdA[0] = ra; L.rdA[1] = ra ^ 64; L.rdW[0] = rw; L.rdW[1] = rw ^ 64;
+        L.voffC = 4 * g * L.ldc2 + (EPI == 0 ? 8 : 4) * j;
+        L.voffG = 4 * g * L.ldg2 + 4 * j;
+    }
+    // this wave's pieces cover LDS rows 8 wave .. + 7 of a 64-row group = MFMA columns 8 (wave & 1) .. + 7 of n-tile wave >> 1
+    //   EPI 0: source row 4 j + ni  -> 32 (wave & 1) + (wave >> 1) + 4 (lane >> 3)
+    //   EPI 1: n-tiles 0, 1: val row 2 j + ni; n-tiles 2, 3: gate row F + 2 j + (ni - 2)  -> 16 (wave & 1) + (wave >> 1 & 1) [+ F] + 2 (lane >> 3)
+    const int wrow0 = EPI == 0 ? 32 * (wave & 1) + (wave >> 1) : 16 * (wave & 1) + ((wave >> 1) & 1) + (wave >= 4 ? p.N : 0);
+    auto origin = [&](Ctx& c, TileXY t, bool real) {
+        c.nA = real ? szA : 0u; c.nW = real ? szW : 0u;
+        c.sA = (t.tm * 256 + 8 * wave) * L.lda2;
+        c.sW = (t.tn * (EPI == 0 ? 256 : 128) + wrow0) * L.ldw2;
+    };
+    auto out_of = [&](TileXY t) {
+        Out o;
+        o.nC = szC; o.nG = szG;
+        o.c = (t.tm * 256 + 128 * wr) * L.ldc2 + (t.tn * (EPI == 0 ? 256 : 128) + (EPI == 0 ? 64 : 32) * wc) * 2;
+        o.g = EPI == 0 ? 0 : (t.tm * 256 + 128 * wr) * L.ldg2 + (t.tn * 128 + 32 * wc) * 2;
+        return o;
+    };
+    f32x4 acc[8][4];
+    Frags f;
+    const int NT = p.K >> 6;                                 // even, >= 6 (host-checked)
+    TileXY cur = tile_of(x, jw, p.ntm, p.ntn);
+    Ctx c, cn;
+    origin(c, cur, true);
+    stageA(L, c, 0, 0, 0, wave); stageW(L, c, 0, 0, 0, wave); stageW(L, c, 0, 0, 1, wave); stageA(L, c, 0, 0, 1, wave);
+    stageA(L, c, 1, 1, 0, wave); stageW(L, c, 1, 1, 0, wave);
+    GM_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // waves 4..7 run one barrier behind (MFMAs of one group over the other's loads)
+    Out prev{0u, 0u, 0, 0};                                  // the first tile has no predecessor: its "previous rows" go nowhere (zero records)
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < ntile; ++it) {
+        const bool has_next = it + 1 < ntile;
+        const TileXY nxt = tile_of(x, jw + (has_next ? it + 1 : it) * nper, p.ntm, p.ntn);
+        origin(cn, nxt, has_next);
+        const Out ocur = out_of(cur);
+        ktile<EPI, 1>(L, c, 1, c, 2, 0, wave, f, acc, prev, ocur);
+        ktile<EPI, 2>(L, c, 2, c, 3, 1, wave, f, acc, prev, ocur);
+        for (int t = 2; t < NT - 2; t += 2) {
+            ktile<EPI, 0>(L, c, t + 1, c, t + 2, 0, wave, f, acc, prev, ocur);
+            ktile<EPI, 0>(L, c, t + 2, c, t + 3, 1, wave, f, acc, prev, ocur);
+        }
+        ktile<EPI, 0>(L, c, NT - 1, cn, 0, 0, wave, f, acc, prev, ocur);          // t = NT - 2
+        ktile<EPI, 3>(L, cn, 0, cn, 1, 1, wave, f, acc, prev, ocur);              // t = NT - 1
+        prev = ocur;
+        cur = nxt; c = cn;
+    }
+    store_half<EPI, 1, 0>(acc, L, prev);
+    store_half<EPI, 1, 1>(acc, L, prev);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+bool gemm_shape_ok(long M, long N, long K, long lda, long ldw, long ldc, long wrows, int ncol_tile) {
+    if (M <= 0 || N <= 0 || K < 384 || (K % 128) || (N % ncol_tile)) return false;
+    if (lda < K || ldw < K || ldc < wrows || (lda % 8) || (ldw % 8) || (ldc % 2)) return false;
+    // 32-bit byte offsets inside the buffer descriptors, incl. the rows a partial last M-tile addresses beyond M (range-checked away)
+    const long mpad = (M + 255) / 256 * 256;
+    return mpad * lda * 2 < (1L << 32) && wrows * ldw * 2 < (1L << 32) && mpad * ldc * 2 < (1L << 32);
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;                            // (idempotent; racing threads set the same value)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return MMAE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const long tiles = (long)a.ntm * a.ntn;
+    const int nper = tiles >= 256 ? 32 : (int)((tiles + 7) / 8);          // workgroups per XCD group; one workgroup per CU (128 KB of LDS)
+    MMAE_LAUNCH((gemm8p_kernel<EPI>), dim3(8 * nper), dim3(512), 131072, st, a);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+}  // namespace
+
+extern "C" int mmae_gemm_nt_supported(long M, long N, long K, long lda, long ldw, long ldc) {
+    return gemm_shape_ok(M, N, K, lda, ldw, ldc, N, 256) ? 1 : 0;
+}
+
+extern "C" int mmae_gemm_nt(long M, long N, long K, const void* A, long lda, const void* W, long ldw, void* C, long ldc, void* stream) {
+    if (!A || !W || !C || !gemm_shape_ok(M, N, K, lda, ldw, ldc, N, 256)) return MMAE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(C) & 7)) return MMAE_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = (bf16*)C; a.G = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = (int)lda; a.ldw = (int)ldw; a.ldc = (int)ldc; a.ldg = 0;
+    a.ntm = (int)((M + 255) / 256); a.ntn = (int)(N / 256);
+    return launch_gemm<0>(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmae_gemm_geglu_supported(long M, long F, long K, long lda, long ldw, long ldh, long ldg) {
+    return (gemm_shape_ok(M, F, K, lda, ldw, ldh, 2 * F, 128) && ldg >= F && (ldg % 2) == 0 && (M + 255) / 256 * 256 * ldg * 2 < (1L << 32)) ? 1 : 0;
+}
+
+extern "C" int mmae_gemm_geglu(long M, long F, long K, const void* A, long lda, const void* W1, long ldw, void* h, long ldh, void* g, long ldg,
+                               void* stream) {
+    if (!A || !W1 || !h || !g || !mmae_gemm_geglu_supported(M, F, K, lda, ldw, ldh, ldg)) return MMAE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W1) & 15) || (reinterpret_cast<uintptr_t>(h) & 3) ||
+        (reinterpret_cast<uintptr_t>(g) & 3)) return MMAE_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16*)A; a.W = (const bf16*)W1; a.C = (bf16*)h; a.G = (bf16*)g;
+    a.M = (int)M; a.N = (int)F; a.K = (int)K; a.lda = (int)lda; a.ldw = (int)ldw; a.ldc = (int)ldh; a.ldg = (int)ldg;
+    a.ntm = (int)((M + 255) / 256); a.ntn = (int)(F / 128);
+    return launch_gemm<1>(a, reinterpret_cast<hipStream_t>(stream));
+}

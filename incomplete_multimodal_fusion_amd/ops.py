@@ -173,6 +173,66 @@ def join_wgrad_stream():
         torch.cuda.current_stream().wait_stream(s)
 
 
+# ------------------------------------------------------------------------------------------------ own GEMM (csrc/gemm.hip)
+OWN_GEMM = 1          # 1: forward / input-gradient projections of supported shapes run the hand-written persistent 256x256x64 kernel (and
+                      # FeedForward[1] + GEGLU its fused-epilogue form); 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
+_OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
+
+
+def own_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Can y = x @ w^T run on mmae_gemm_nt?  x (M, K), w (N, K): bf16, unit column stride, 16-byte aligned bases, N % 256 == 0,
+    K % 128 == 0, K >= 384, and enough tiles to fill the 256 persistent workgroups."""
+    if not OWN_GEMM or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or not x.is_cuda:
+        return False
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or x.stride(1) != 1 or w.stride(1) != 1 or x.data_ptr() % 16 or w.data_ptr() % 16:
+        return False
+    if ((M + 255) // 256) * (N // 256) < _OWN_GEMM_MIN_TILES:
+        return False
+    return bool(_lib.lib().mmae_gemm_nt_supported(M, N, K, x.stride(0), w.stride(0), N))
+
+
+def gemm_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y (M, N) = x (M, K) @ w (N, K)^T on the own kernel (caller checked own_gemm_ok).  No autograd."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if out is None else out
+    assert y.shape == (M, N) and y.stride(1) == 1 and y.dtype == torch.bfloat16
+    call("mmae_gemm_nt", M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(y), y.stride(0), stream())
+    return y
+
+
+def matmul_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ w^T: the own kernel where it applies, the library GEMM (hipBLASLt through torch) otherwise."""
+    if own_gemm_ok(x, w):
+        return gemm_nt(x, w, out)
+    if out is not None:
+        return torch.mm(x, w.t(), out=out)
+    return torch.nn.functional.linear(x, w)
+
+
+def own_geglu_ok(y: torch.Tensor, w1: torch.Tensor) -> bool:
+    if not OWN_GEMM or y.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or y.dim() != 2 or not y.is_cuda:
+        return False
+    M, K = y.shape
+    F2 = w1.shape[0]
+    if F2 % 2 or w1.shape[1] != K or y.stride(1) != 1 or w1.stride(1) != 1 or y.data_ptr() % 16 or w1.data_ptr() % 16:
+        return False
+    F = F2 // 2
+    if ((M + 255) // 256) * (F // 128) < _OWN_GEMM_MIN_TILES:
+        return False
+    return bool(_lib.lib().mmae_gemm_geglu_supported(M, F, K, y.stride(0), w1.stride(0), 2 * F, F))
+
+
+def gemm_geglu(y: torch.Tensor, w1: torch.Tensor, h: torch.Tensor, g: torch.Tensor):
+    """h (M, 2F) = y @ w1^T and g (M, F) = gelu(h[:, F:]) * h[:, :F] in one kernel (FeedForward[1] + GEGLU, zorro_utils.py:115-126)."""
+    M, K = y.shape
+    F = w1.shape[0] // 2
+    assert h.shape == (M, 2 * F) and g.shape == (M, F) and h.stride(1) == 1 and g.stride(1) == 1
+    call("mmae_gemm_geglu", M, F, K, ptr(y), y.stride(0), ptr(w1), w1.stride(0), ptr(h), h.stride(0), ptr(g), g.stride(0), stream())
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ cat(ws)^T (+ bias) on hipBLASLt/rocBLAS through torch.  `ws` are the fp32 master weights (cast to the
     compute dtype here); the weight gradient comes back in fp32 straight from a split-K batched GEMM."""
@@ -191,7 +251,11 @@ class _Linear(torch.autograd.Function):
             b = bias._mmae_shadow if (T == torch.bfloat16 and hasattr(bias, "_mmae_shadow")) else \
                 (bias if bias.dtype == T else bias.to(T))
         with torch.autocast("cuda", enabled=False):
-            y = torch.nn.functional.linear(x, w, b)
+            x2o = x.reshape(-1, x.shape[-1]) if b is None else None
+            if x2o is not None and own_gemm_ok(x2o, w):
+                y = gemm_nt(x2o, w).reshape(*x.shape[:-1], w.shape[0])
+            else:
+                y = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
         # in-place flat gradient only for weights used ONCE per step: a second use would overwrite the first gradient
         ctx.gview = grad_view_of(ws) if (once and all(wi.dtype == torch.float32 for wi in ws)) else None
@@ -214,7 +278,7 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 from .engine import shadow_t_of
                 wt = shadow_t_of(ctx.ws, w.dtype)            # engine: W^T is maintained by one batched launch per step
-                gx = torch.nn.functional.linear(g2, wt if wt is not None else w.t().contiguous()).reshape(x.shape)
+                gx = matmul_nt(g2, wt if wt is not None else w.t().contiguous()).reshape(x.shape)
             gws = [None] * len(sizes)
             if any(ctx.needs_input_grad[3:]):
                 # The weight gradient is off the critical path (nothing in this backward pass reads it) and MFMA-bound,
@@ -298,8 +362,8 @@ class _KvQ(torch.autograd.Function):
         wkv_c = shadow_of((wkv,), T)
         wkv_c = wkv_c if wkv_c is not None else (wkv if wkv.dtype == T else wkv.to(T))
         with torch.autocast("cuda", enabled=False):
-            kv = torch.nn.functional.linear(z, wkv_c)
-            q = torch.nn.functional.linear(z[r0:r0 + n], wq_c)
+            kv = matmul_nt(z, wkv_c)
+            q = matmul_nt(z[r0:r0 + n], wq_c)
         ctx.save_for_backward(z, wq_c, wkv_c)
         ctx.wkv, ctx.wq = wkv, wq
         ctx.cfg = (r0, n, grad_view_of((wq,)) if wq.dtype == torch.float32 else None,
@@ -315,7 +379,7 @@ class _KvQ(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             from .engine import shadow_t_of
             wt = shadow_t_of((ctx.wkv,), wkv_c.dtype)
-            gz = torch.nn.functional.linear(gkv, wt if wt is not None else wkv_c.t().contiguous())
+            gz = matmul_nt(gkv, wt if wt is not None else wkv_c.t().contiguous())
             zs = gz[r0:r0 + n]
             torch.addmm(zs, gq, wq_c, out=zs)
             gwkv = _wgrad(gkv, z, gvkv)
@@ -354,7 +418,7 @@ class _KvCtx(torch.autograd.Function):
         wc = torch.cat([cast(w) for w in ws], dim=0)
         bc = torch.cat([b if b.dtype == T else b.to(T) for b in bs], dim=0) if bs else None
         with torch.autocast("cuda", enabled=False):
-            kv = torch.nn.functional.linear(z, wkv_c)
+            kv = matmul_nt(z, wkv_c)
             c = torch.nn.functional.linear(z[r0:r0 + n], wc, bc)
         ctx.save_for_backward(z, wkv_c, wc)
         ctx.wkv = wkv
@@ -373,7 +437,7 @@ class _KvCtx(torch.autograd.Function):
             gz = None
             if ctx.needs_input_grad[0]:
                 wt = shadow_t_of((ctx.wkv,), wkv_c.dtype)
-                gz = torch.nn.functional.linear(gkv, wt if wt is not None else wkv_c.t().contiguous())
+                gz = matmul_nt(gkv, wt if wt is not None else wkv_c.t().contiguous())
                 zs = gz[r0:r0 + n]
                 torch.addmm(zs, gc, wc, out=zs)
             need_kv = ctx.needs_input_grad[3]                      # a frozen weight gets no gradient (and no flat-buffer write)
@@ -894,9 +958,12 @@ class _FeedForwardGEGLU(torch.autograd.Function):
         f = torch.empty(rows, w2.shape[0], dtype=T, device=y.device)
         with torch.autocast("cuda", enabled=False):
             for a, b in _row_chunks(rows, FF_CHUNKS):
-                torch.mm(y[a:b], w1c.t(), out=h[a:b])
-                call("mmae_geglu_fwd", dt(T), b - a, F, ptr(h[a:b]), ptr(g[a:b]), stream())
-                torch.mm(g[a:b], w2c.t(), out=f[a:b])
+                if own_geglu_ok(y[a:b], w1c):
+                    gemm_geglu(y[a:b], w1c, h[a:b], g[a:b])         # FeedForward[1] + GEGLU in one kernel (csrc/gemm.hip)
+                else:
+                    matmul_nt(y[a:b], w1c, out=h[a:b])
+                    call("mmae_geglu_fwd", dt(T), b - a, F, ptr(h[a:b]), ptr(g[a:b]), stream())
+                matmul_nt(g[a:b], w2c, out=f[a:b])
         ctx.save_for_backward(y, h, g, w1c, w2c)
         f32 = w1.dtype == torch.float32 and w2.dtype == torch.float32
         ctx.cfg = (w1, w2, grad_view_of((w1,)) if f32 else None, grad_view_of((w2,)) if f32 else None)
@@ -920,10 +987,10 @@ class _FeedForwardGEGLU(torch.autograd.Function):
             chunks = _row_chunks(rows, FF_CHUNKS)
             dg = torch.empty(max(b - a for a, b in chunks), F, dtype=T, device=y.device)
             for a, b in chunks:
-                torch.mm(df[a:b], w2t.t(), out=dg[:b - a])                # dg = df @ W2
+                matmul_nt(df[a:b], w2t, out=dg[:b - a])                   # dg = df @ W2
                 call("mmae_geglu_bwd", dt(T), b - a, F, ptr(h[a:b]), ptr(dg), ptr(dh[a:b]), stream())
                 if dy is not None:
-                    torch.mm(dh[a:b], w1t.t(), out=dy[a:b])               # dy = dh @ W1
+                    matmul_nt(dh[a:b], w1t, out=dy[a:b])                  # dy = dh @ W1
             gw2 = _wgrad(df, g, gv2)
             gw1 = _wgrad(dh, y, gv1)
         if gv1 is not None and gv2 is not None:

@@ -9,7 +9,8 @@ import torch
 from incomplete_multimodal_fusion_amd import _lib
 
 QUERIES = {"mmae_abi_version", "mmae_last_hip_error", "mmae_modattn_bwd_nsplit",
-           "mmae_add_ln_bwd_ws_floats", "mmae_hardneg_ws_floats"}          # setters / size queries: no pointers to validate
+           "mmae_add_ln_bwd_ws_floats", "mmae_hardneg_ws_floats", "mmae_mha_bwd_ws_floats",
+           "mmae_gemm_nt_supported", "mmae_gemm_geglu_supported"}           # setters / size / shape queries: no pointers to validate
 
 
 def test_every_entry_point_rejects_null_pointers():
@@ -53,6 +54,23 @@ def test_row_kernel_argument_checks():
     off = (ctypes.c_long * 15)()
     assert l.mmae_descriptor_layout(2, 3, 16, 24, off) == off[14] > 0
     assert l.mmae_descriptor_layout(-1, 3, 16, 24, off) == -1
+
+
+def test_gemm_argument_checks():
+    l = _lib.lib()
+    buf = (ctypes.c_char * 4096)()
+    a16 = (ctypes.addressof(buf) + 15) // 16 * 16
+    P = ctypes.c_void_p
+    ok = lambda *a: l.mmae_gemm_nt_supported(*a)
+    assert ok(163840, 4096, 768, 768, 768, 4096) == 1 and ok(1000, 256, 384, 384, 384, 256) == 1
+    assert ok(1024, 300, 768, 768, 768, 300) == 0 and ok(1024, 256, 320, 320, 320, 256) == 0 and ok(1024, 256, 768, 760, 768, 256) == 0
+    assert l.mmae_gemm_nt(1024, 256, 768, P(a16), 768, P(a16), 768, P(a16 + 4), 256, None) == -1      # C must be 8-byte aligned
+    assert l.mmae_gemm_nt(1024, 256, 768, P(a16 + 8), 768, P(a16), 768, P(a16), 256, None) == -1      # A must be 16-byte aligned
+    assert l.mmae_gemm_nt(1024, 250, 768, P(a16), 768, P(a16), 768, P(a16), 250, None) == -1
+    assert l.mmae_gemm_geglu_supported(4096, 2048, 768, 768, 768, 4096, 2048) == 1
+    assert l.mmae_gemm_geglu_supported(4096, 2000, 768, 768, 768, 4000, 2000) == 0                    # F % 128
+    assert l.mmae_gemm_geglu(4096, 2048, 768, P(a16), 768, P(a16), 768, P(a16), 4096, None, 2048, None) == -1
+    assert l.mmae_mha_bwd_ws_floats(8, 1000) == 24000 and l.mmae_mha_bwd_ws_floats(0, 5) == -1
 
 
 def test_binding_raises_and_refuses_host_tensors():

@@ -17,7 +17,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "missing export: " + name
-    assert _lib.lib().mmae_abi_version() == 3
+    assert _lib.lib().mmae_abi_version() == 4
     # pure host helpers (no GPU needed)
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(1000, 768) == 250 * 4 * 768
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(40960, 768) == 1024 * 4 * 768
@@ -64,11 +64,13 @@ def build_model(cfg, channels):
     oa = {d: SpatialOutputAdapter(num_channels=c, stride_level=1, patch_size_full=cfg["patch_size"],
                                   dim_tokens=cfg["decoder_dim"], depth=cfg["decoder_depth"],
                                   num_heads=cfg["decoder_heads"], use_task_queries=True, task=d,
-                                  context_tasks=list(doms), use_xattn=True) for d, c in channels}
+                                  context_tasks=list(doms), use_xattn=True,
+                                  drop_path_rate=cfg.get("decoder_drop_path_rate", 0.0)) for d, c in channels}
     P = (cfg["image_size"] // cfg["patch_size"]) ** 2
     return MultiMAE(ia, oa, num_global_tokens=1, dim_tokens=cfg["dim_tokens"], depth=cfg["depth"],
                     dim_head=cfg["dim_head"], heads=cfg["heads"], ff_mult=4, num_fusion_tokens=P,
-                    return_token_types=(TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION))
+                    return_token_types=(TokenTypes.S1, TokenTypes.S2, TokenTypes.DEM, TokenTypes.FUSION),
+                    drop_path_rate=cfg.get("drop_path_rate", 0.0))
 
 
 def test_state_dict_abi_matches_reference(g_e2e):

@@ -1,0 +1,89 @@
+"""The hand-written persistent GEMM (csrc/gemm.hip: mmae_gemm_nt, mmae_gemm_geglu) against plain torch references.
+
+Numerics bar: bf16 operands, fp32 accumulation, bf16 result -- compared with the SAME product evaluated by torch in fp32 from the bf16
+operands (the kernel's only freedom is the summation order and the final rounding): max-abs error within 1e-2 of max|ref| (north_star's
+bf16 bar), and within ~1.5 bf16 ulps of the result's own magnitude element-wise for the bulk (mean error check).  Shapes cover: M tails
+(partial last tile), one tile per workgroup and many, the minimum K (6 K-tiles) and long K, N of 1..16 tiles (every XCD-order branch),
+leading dimensions larger than the row (column blocks of wider matrices), and the encoder's own projection shapes."""
+import pytest
+import torch
+
+from tests.test_gpu_kernels import DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _operands(M, N, K, lda=None, ldw=None, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    lda, ldw = lda or K, ldw or K
+    a = (torch.rand(M, lda, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    w = (torch.rand(N, ldw, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    return a[:, :K], w[:, :K]
+
+
+SHAPES = [(256, 256, 384), (1000, 512, 512), (2597, 768, 768), (4096, 1536, 768), (8192, 768, 2048), (5000, 256, 4096),
+          (66000, 2304, 384), (70016, 768, 512), (16384, 4096, 768), (9999, 2560, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_matches_fp32_reference(M, N, K):
+    from incomplete_multimodal_fusion_amd import _lib, ops
+    a, w = _operands(M, N, K, seed=M + N + K)
+    assert _lib.lib().mmae_gemm_nt_supported(M, N, K, a.stride(0), w.stride(0), N)
+    y = ops.gemm_nt(a, w)
+    ref = a.float() @ w.float().t()
+    close(y, ref, 1e-2, "gemm %s" % ((M, N, K),))
+    # the bulk is at rounding level: bf16 has 8 significand bits -> relative error <= 2^-9 per element after one rounding
+    err = (y.float() - ref).abs()
+    assert float((err / (ref.abs() + 1e-3)).median()) < 4e-3
+    assert torch.equal(y, y.clone()) and torch.isfinite(y.float()).all()
+    # bitwise reproducible (fixed tile order and summation order, no atomics)
+    assert torch.equal(ops.gemm_nt(a, w), y)
+
+
+def test_gemm_nt_leading_dimensions_and_output_view():
+    """Operands that are column blocks of wider matrices (lda / ldw > K) and an output written into a column block (ldc > N): the untouched
+    columns of the output matrix must stay untouched."""
+    from incomplete_multimodal_fusion_amd import ops
+    M, N, K = 3000, 512, 768
+    a, w = _operands(M, N, K, lda=K + 64, ldw=K + 8, seed=5)
+    big = torch.full((M, N + 256), 7.0, device=DEV, dtype=torch.bfloat16)
+    out = big[:, 128:128 + N]
+    assert out.data_ptr() % 8 == 0
+    ops.gemm_nt(a, w, out=out)
+    close(out, a.float() @ w.float().t(), 1e-2, "strided gemm")
+    assert float((big[:, :128].float() - 7).abs().max()) == 0.0 and float((big[:, 128 + N:].float() - 7).abs().max()) == 0.0
+
+
+def test_gemm_nt_rejects_unsupported_shapes():
+    from incomplete_multimodal_fusion_amd import _lib, ops
+    lib = _lib.lib()
+    assert not lib.mmae_gemm_nt_supported(1024, 300, 768, 768, 768, 300)          # N not a multiple of 256
+    assert not lib.mmae_gemm_nt_supported(1024, 256, 320, 320, 320, 256)          # K below six K-tiles
+    assert not lib.mmae_gemm_nt_supported(1024, 256, 448, 448, 448, 256)          # K not a multiple of 128
+    assert not lib.mmae_gemm_nt_supported(1 << 20, 4096, 768, 768, 768, 4096)     # byte offsets beyond 32 bits
+    a, w = _operands(512, 300, 768)
+    with pytest.raises(_lib.MmaeLibraryError):
+        ops.gemm_nt(a, w)
+    # the dispatcher falls back to the library GEMM instead
+    close(ops.matmul_nt(a, w), a.float() @ w.float().t(), 1e-2, "fallback")
+
+
+@pytest.mark.parametrize("M,F,K", [(256, 128, 384), (3001, 256, 768), (16384, 2048, 768), (40000, 1024, 512)])
+def test_gemm_geglu_matches_separate_path(M, F, K):
+    """FeedForward[1] + GEGLU in one kernel (zorro_utils.py:115-126): h against the fp32 product, g against (a) the exact-erf formula on
+    the kernel's own bf16 h -- the contract: g is what mmae_geglu_fwd computes from h -- and (b) the fp64 composition from scratch."""
+    from incomplete_multimodal_fusion_amd import _lib, ops
+    from oracle import mmae_oracle as O
+    a, w1 = _operands(M, 2 * F, K, seed=M + F)
+    assert _lib.lib().mmae_gemm_geglu_supported(M, F, K, a.stride(0), w1.stride(0), 2 * F, F)
+    h = torch.full((M, 2 * F), float("nan"), device=DEV, dtype=torch.bfloat16)
+    g = torch.full((M, F), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.gemm_geglu(a, w1, h, g)
+    ref_h = a.float() @ w1.float().t()
+    close(h, ref_h, 1e-2, "h")
+    sep = ops.geglu(h)                                               # the separate kernel on the same h
+    assert float((g.float() - sep.float()).abs().max()) <= 2 ** -7 * max(float(sep.float().abs().max()), 1e-6), "g vs geglu(h)"
+    assert float(((g.float() - sep.float()).abs() > 0).float().mean()) < 1e-3     # same formula, same rounding: (almost) bit-identical
+    h64 = ref_h.double()
+    close(g, O.gelu_erf(h64[:, F:]) * h64[:, :F], 1e-2, "g vs fp64")
