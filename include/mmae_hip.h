@@ -24,7 +24,7 @@ extern "C" {
 #define MMAE_BF16 1
 #define MMAE_ABI_VERSION 4   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
                                 mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
-                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu */
+                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -105,10 +105,16 @@ int mmae_geglu_fwd(int dtype, long rows, int F, const void* h, void* out, void* 
 int mmae_geglu_bwd(int dtype, long rows, int F, const void* h, const void* gout, void* dh, void* stream);
 /* ---- dense projections (the nn.Linear calls of DSI-MM/zorro_utils.py:181-182,192 (to_q / to_kv / to_out), :125-127 (FeedForward) and
  * autograd's dX = dY . W for them): C[M, N] = A[M, K] . W[N, K]^T, bf16 in / bf16 out, fp32 accumulate, rows contiguous with leading
- * dimensions lda / ldw / ldc (elements).  Shapes: any M, N % 256 == 0, K % 128 == 0, K >= 384, every byte offset < 4 GiB --
+ * dimensions lda / ldw / ldc (elements).  Shapes: any M, N % 256 == 0, K % 128 == 0, K >= 384, every byte offset < 2 GiB --
  * mmae_gemm_nt_supported() says whether a shape qualifies (callers use the library GEMM otherwise).  One persistent launch, 128 KB LDS. */
 int mmae_gemm_nt_supported(long M, long N, long K, long lda, long ldw, long ldc);
 int mmae_gemm_nt(long M, long N, long K, const void* A, long lda, const void* W, long ldw, void* C, long ldc, void* stream);
+/* Weight gradients of the same layers (autograd's dW = dY^T X): out[N, Kin] (fp32) = G[rows, N]^T . X[rows, Kin], bf16 operands contracted
+ * over their rows (transposing LDS reads), split-K over workgroups with the fp32 slabs summed in a fixed order (bitwise reproducible).
+ * N % 256 == 0, Kin % 256 == 0, rows >= 128, byte offsets < 2 GiB.  ws: mmae_gemm_tn_ws_floats(rows, N, Kin) floats (may be 0 -> NULL). */
+int mmae_gemm_tn_supported(long rows, long N, long Kin, long ldg, long ldx);
+long mmae_gemm_tn_ws_floats(long rows, long N, long Kin);
+int mmae_gemm_tn(long rows, long N, long Kin, const void* G, long ldg, const void* X, long ldx, float* out, float* ws, void* stream);
 /* FeedForward[1] + GEGLU in one kernel (DSI-MM/zorro_utils.py:115-118,125-126): W1 is (2 F, K), val rows [0, F), gate rows [F, 2 F);
  * h[M, 2 F] = A . W1^T (kept: the backward's GEGLU' reads it) and g[M, F] = gelu(h[:, F + n]) * h[:, n] from the bf16-rounded h, i.e.
  * exactly what mmae_geglu_fwd computes from h.  F % 128 == 0; the other constraints as above. */

@@ -310,9 +310,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
 bool gemm_shape_ok(long M, long N, long K, long lda, long ldw, long ldc, long wrows, int ncol_tile) {
     if (M <= 0 || N <= 0 || K < 384 || (K % 128) || (N % ncol_tile)) return false;
     if (lda < K || ldw < K || ldc < wrows || (lda % 8) || (ldw % 8) || (ldc % 2)) return false;
-    // 32-bit byte offsets inside the buffer descriptors, incl. the rows a partial last M-tile addresses beyond M (range-checked away)
+    // 31-bit byte offsets inside the buffer descriptors, incl. the rows a partial last M-tile addresses beyond M (range-checked away)
     const long mpad = (M + 255) / 256 * 256;
-    return mpad * lda * 2 < (1L << 32) && wrows * ldw * 2 < (1L << 32) && mpad * ldc * 2 < (1L << 32);
+    return mpad * lda * 2 < (1L << 31) && wrows * ldw * 2 < (1L << 31) && mpad * ldc * 2 < (1L << 31);      // (int offset arithmetic in the kernel)
 }
 
 template <int EPI>
@@ -346,7 +346,7 @@ extern "C" int mmae_gemm_nt(long M, long N, long K, const void* A, long lda, con
 }
 
 extern "C" int mmae_gemm_geglu_supported(long M, long F, long K, long lda, long ldw, long ldh, long ldg) {
-    return (gemm_shape_ok(M, F, K, lda, ldw, ldh, 2 * F, 128) && ldg >= F && (ldg % 2) == 0 && (M + 255) / 256 * 256 * ldg * 2 < (1L << 32)) ? 1 : 0;
+    return (gemm_shape_ok(M, F, K, lda, ldw, ldh, 2 * F, 128) && ldg >= F && (ldg % 2) == 0 && (M + 255) / 256 * 256 * ldg * 2 < (1L << 31)) ? 1 : 0;
 }
 
 extern "C" int mmae_gemm_geglu(long M, long F, long K, const void* A, long lda, const void* W1, long ldw, void* h, long ldh, void* g, long ldg,
@@ -359,4 +359,230 @@ extern "C" int mmae_gemm_geglu(long M, long F, long K, const void* A, long lda, 
     a.M = (int)M; a.N = (int)F; a.K = (int)K; a.lda = (int)lda; a.ldw = (int)ldw; a.ldc = (int)ldh; a.ldg = (int)ldg;
     a.ntm = (int)((M + 255) / 256); a.ntn = (int)(F / 128);
     return launch_gemm<1>(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+// =====================================================================================================================================
+// Weight gradients: dW[N, Kin] = G[rows, N]^T . X[rows, Kin] (bf16 in, fp32 out) -- autograd's dW = dY^T X of the same nn.Linear layers.
+// Both operands are contracted over their ROW index, so a K-tile is 64 rows of G and of X, staged row-major exactly as they lie in HBM
+// ([64 r][256 columns], 512-byte rows, 1 KiB LDS-DMA pieces = 2 rows) and every MFMA fragment is fetched with the hardware transpose read
+// ds_read_b64_tr_b16 (two per fragment: 4 rows x 16 columns each, column-major to the lanes).  Swizzle: the 32-byte column-tile index of a
+// row is XORed with m(row) = (row & 3) | ((row >> 3 & 1) << 2) on the DMA source and on the read address -- the 32 lanes of a half-wave
+// then touch 8 rows x 32 bytes on 64 distinct banks (conflict-free), and m does not change between a fragment's two reads (rows + 4) nor
+// between the k-steps (rows + 32): one v_xor per fragment address, everything else is an immediate offset.
+// Same pipeline as above (8 waves, 2 LDS buffers, staggered wave groups, counted vmcnt), but the phases of a K-tile are (k-step, M half):
+// rows 0..31 of both tiles are read in phases 0 / 1 and restaged in phase 3 / phase 0 of the next K-tile, rows 32..63 in phases 2 / 3 and
+// restaged in phases 1 / 2 -- so the counted waits sit in phases 1 and 3 with three staging steps in flight each.
+// The output has few tiles (6..48) while the contraction is 65k..165k rows long: SPLIT-K over workgroups -- (tile, split) pairs fill the
+// 256 CUs, each writes its fp32 partial tile into slab `split`, and splitk_sum_f32_kernel adds the slabs in a fixed order (no atomics:
+// bitwise reproducible).  No rolling epilogue: one tile per workgroup, 500+ K-tiles each.
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct TnArgs {
+    const bf16* G; const bf16* X; float* P;      // P: S slabs of (N, Kin) fp32 (S == 1: the destination itself)
+    int rows, N, Kin, ldg, ldx;
+    int tkin, T, S, rows_per_split;              // tiles along Kin, tiles in all, splits, rows per split (multiple of 128)
+};
+
+__device__ __forceinline__ bf16x8 tn_frag(const char* p) {          // rows R..R+3 and R+4..R+7 of one 16-column tile -> 8 k-slots
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + 2048));
+    s16x8 x;
+    x[0] = lo[0]; x[1] = lo[1]; x[2] = lo[2]; x[3] = lo[3]; x[4] = hi[0]; x[5] = hi[1]; x[6] = hi[2]; x[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, x);
+}
+
+struct TnLane {
+    char* lds;
+    const bf16* G; const bf16* X;
+    unsigned nG, nX;                 // record counts: bytes up to the end of this split's last row (later rows read as zero)
+    int voffG[2], voffX[2];          // per-lane DMA source offsets of the two pieces of a staging step (rows 4 w + half, + 2: m differs in bit 1)
+    int sG, sX;                      // scalar byte offsets: this split's first row + this wave's rows inside a 32-row block, tile column origin
+    int ldg2, ldx2;
+    int lpA, lpB;                    // fragment read bases: (8 g + q) * 512 + 8 p, XORed with 32 m and the wave's column-tile origin
+};
+
+// rows 32 blk .. + 31 of K-tile kt of operand G (which = 0) / X (1) into buffer buf: wave w brings rows 4 w .. 4 w + 3 of the block
+__device__ __forceinline__ void tn_stage(const TnLane& L, int which, int kt, int blk, int buf, int wave) {
+    const int row = 32 * blk + 4 * wave;
+    char* dst = L.lds + buf * 65536 + which * 32768 + row * 512;
+    const int ld2 = which ? L.ldx2 : L.ldg2;
+    const int so = (which ? L.sX : L.sG) + (kt * 64 + 32 * blk) * ld2;
+    const void* base = which ? (const void*)L.X : (const void*)L.G;
+    const unsigned n = which ? L.nX : L.nG;
+    gm_dma(base, n, which ? L.voffX[0] : L.voffG[0], so, dst);
+    gm_dma(base, n, which ? L.voffX[1] : L.voffG[1], so + 2 * ld2, dst + 1024);
+}
+
+struct TnFrags { bf16x8 a[4], b[4]; };
+
+// phase (KS, QA): k-step KS (rows 32 KS .. + 31), the wave's n-tiles 4 QA .. + 3 against its 4 kin-tiles
+template <int KS, int QA>
+__device__ __forceinline__ void tn_load(const TnLane& L, int buf, TnFrags& f) {
+    const char* base = L.lds + buf * 65536 + KS * 16384;
+    if (QA == 0) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) f.b[tj] = tn_frag(base + 32768 + (L.lpB ^ (tj * 32)));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) f.a[ti] = tn_frag(base + (L.lpA ^ ((4 * QA + ti) * 32)));
+}
+template <int QA>
+__device__ __forceinline__ void tn_mfma(const TnFrags& f, f32x4 (&acc)[8][4]) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            acc[4 * QA + ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ti], f.b[tj], acc[4 * QA + ti][tj], 0, 0, 0);
+}
+#define TN_PHASE_TAIL(QA)                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_barrier();                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_setprio(1);                                         \
+    tn_mfma<QA>(f, acc);                                                   \
+    __builtin_amdgcn_s_setprio(0);                                         \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_barrier();                                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+// K-tile t in buffer b.  Staging order: ... G rows 0..31 of t+2 in phase 3, X rows 0..31 of t+1 in phase 0, G rows 32..63 of t+1 in phase 1,
+// X rows 32..63 of t+1 in phase 2: a block is restaged >= 2 phases after its last read; the waits (phase 1: rows 32..63 of THIS K-tile,
+// phase 3: rows 0..31 of the next) leave 3 staging steps = 6 DMA in flight.  K-tiles beyond the split's last row stage zeros (range check).
+__device__ __forceinline__ void tn_ktile(const TnLane& L, int t, int b, int wave, TnFrags& f, f32x4 (&acc)[8][4]) {
+    tn_load<0, 0>(L, b, f);
+    tn_stage(L, 1, t + 1, 0, b ^ 1, wave);
+    TN_PHASE_TAIL(0)
+    tn_load<0, 1>(L, b, f);
+    tn_stage(L, 0, t + 1, 1, b ^ 1, wave);
+    GM_VMCNT(6);
+    TN_PHASE_TAIL(1)
+    tn_load<1, 0>(L, b, f);
+    tn_stage(L, 1, t + 1, 1, b ^ 1, wave);
+    TN_PHASE_TAIL(0)
+    tn_load<1, 1>(L, b, f);
+    tn_stage(L, 0, t + 2, 0, b, wave);
+    GM_VMCNT(6);
+    TN_PHASE_TAIL(1)
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // bijective XCD-aware order: the workgroups of one XCD group take consecutive (split, tile) pairs -- mostly ONE split, i.e. the same
+    // rows of G and X through that XCD's L2
+    const int nwg = gridDim.x, x = blockIdx.x & 7, idx = blockIdx.x >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + idx;
+    const int split = lin / p.T, tile = lin - split * p.T;
+    const int tn = tile / p.tkin, tk = tile - tn * p.tkin;
+    const int r_begin = split * p.rows_per_split, r_end = min(p.rows, r_begin + p.rows_per_split);
+    const int NT = ((r_end - r_begin + 127) >> 7) << 1;                  // K-tiles of 64 rows, rounded up to even (the tail stages zeros)
+    TnLane L;
+    L.lds = lds; L.G = p.G; L.X = p.X;
+    L.ldg2 = p.ldg * 2; L.ldx2 = p.ldx * 2;
+    L.nG = (unsigned)(((long)(r_end - 1) * p.ldg + p.N) * 2);
+    L.nX = (unsigned)(((long)(r_end - 1) * p.ldx + p.Kin) * 2);
+    {
+        const int half = lane >> 5, ch = lane & 31;
+        const int m0 = half | (((wave >> 1) & 1) << 2);                   // m(row) of piece 0's rows 4 w + half (piece 1: rows + 2 -> m ^ 2)
+        L.voffG[0] = half * L.ldg2 + 16 * (ch ^ (m0 << 1)); L.voffG[1] = half * L.ldg2 + 16 * (ch ^ ((m0 ^ 2) << 1));
+        L.voffX[0] = half * L.ldx2 + 16 * (ch ^ (m0 << 1)); L.voffX[1] = half * L.ldx2 + 16 * (ch ^ ((m0 ^ 2) << 1));
+        L.sG = (r_begin + 4 * wave) * L.ldg2 + tn * 512;
+        L.sX = (r_begin + 4 * wave) * L.ldx2 + tk * 512;
+        const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+        const int m = qq | ((g & 1) << 2);
+        const int lp = (8 * g + qq) * 512 + 8 * pp;
+        L.lpA = lp ^ (32 * m) ^ (256 * wr);                               // n-tiles 8 wr .. of the G tile
+        L.lpB = lp ^ (32 * m) ^ (128 * wc);                               // kin-tiles 4 wc .. of the X tile
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TnFrags f;
+    tn_stage(L, 0, 0, 0, 0, wave); tn_stage(L, 1, 0, 0, 0, wave); tn_stage(L, 0, 0, 1, 0, wave); tn_stage(L, 1, 0, 1, 0, wave);
+    tn_stage(L, 0, 1, 0, 1, wave);
+    GM_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < NT; t += 2) {
+        tn_ktile(L, t, 0, wave, f, acc);
+        tn_ktile(L, t + 1, 1, wave, f, acc);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    GM_VMCNT(0);                                                          // the zero-fill staging of the (non-existent) K-tiles NT, NT + 1
+    // acc[it][jt][reg] = dW[tn 256 + 128 wr + 16 it + 4 g + reg][tk 256 + 64 wc + 16 jt + (lane & 15)]: once per workgroup
+    float* out = p.P + (long)split * p.N * p.Kin + ((long)tn * 256 + 128 * wr + 4 * (lane >> 4)) * p.Kin + tk * 256 + 64 * wc + (lane & 15);
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) out[(long)(16 * it + reg) * p.Kin + 16 * jt] = acc[it][jt][reg];
+}
+
+__global__ __launch_bounds__(256) void splitk_sum_f32_kernel(const float* __restrict__ part, int S, long n, float* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 a = *reinterpret_cast<const f32x4*>(part + i);
+    for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(part + (long)s * n + i);      // fixed order: reproducible
+    *reinterpret_cast<f32x4*>(out + i) = a;
+}
+
+struct TnPlan { int tkin, T, S, rps; };
+bool tn_plan(long rows, long N, long Kin, long ldg, long ldx, TnPlan* pl) {
+    if (rows < 128 || N <= 0 || Kin <= 0 || (N % 256) || (Kin % 256) || ldg < N || ldx < Kin || (ldg % 8) || (ldx % 8)) return false;
+    if ((rows + 256) * ldg * 2 >= (1L << 31) || (rows + 256) * ldx * 2 >= (1L << 31) || N * Kin >= (1L << 31)) return false;   // int offsets
+    const long T = (N / 256) * (Kin / 256);
+    long S = T >= 256 ? 1 : 256 / T;
+    const long max_s = rows / 2048 > 0 ? rows / 2048 : 1;                 // at least 32 K-tiles per split
+    if (S > max_s) S = max_s;
+    long rps = (rows + S - 1) / S;
+    rps = (rps + 127) / 128 * 128;
+    S = (rows + rps - 1) / rps;                                           // no empty split
+    pl->tkin = (int)(Kin / 256); pl->T = (int)T; pl->S = (int)S; pl->rps = (int)rps;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int mmae_gemm_tn_supported(long rows, long N, long Kin, long ldg, long ldx) {
+    TnPlan pl;
+    return tn_plan(rows, N, Kin, ldg, ldx, &pl) ? 1 : 0;
+}
+// fp32 workspace for the split-K slabs (0 when the shape runs unsplit or is unsupported)
+extern "C" long mmae_gemm_tn_ws_floats(long rows, long N, long Kin) {
+    TnPlan pl;
+    if (!tn_plan(rows, N, Kin, N, Kin, &pl)) return 0;
+    return pl.S > 1 ? (long)pl.S * N * Kin : 0;
+}
+extern "C" int mmae_gemm_tn(long rows, long N, long Kin, const void* G, long ldg, const void* X, long ldx, float* out, float* ws, void* stream) {
+    TnPlan pl;
+    if (!G || !X || !out || !tn_plan(rows, N, Kin, ldg, ldx, &pl)) return MMAE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(G) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return MMAE_ERR_ARG;
+    if (pl.S > 1 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 15))) return MMAE_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_tn8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return MMAE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    TnArgs a{};
+    a.G = (const bf16*)G; a.X = (const bf16*)X; a.P = pl.S > 1 ? ws : out;
+    a.rows = (int)rows; a.N = (int)N; a.Kin = (int)Kin; a.ldg = (int)ldg; a.ldx = (int)ldx;
+    a.tkin = pl.tkin; a.T = pl.T; a.S = pl.S; a.rows_per_split = pl.rps;
+    MMAE_LAUNCH(gemm_tn8p_kernel, dim3(pl.T * pl.S), dim3(512), 131072, st, a);
+    MMAE_CHECK_LAUNCH();
+    if (pl.S > 1) {
+        const long n = N * Kin;
+        MMAE_LAUNCH(splitk_sum_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, pl.S, n, out);
+        MMAE_CHECK_LAUNCH();
+    }
+    return MMAE_OK;
 }

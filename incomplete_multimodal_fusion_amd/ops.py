@@ -174,15 +174,16 @@ def join_wgrad_stream():
 
 
 # ------------------------------------------------------------------------------------------------ own GEMM (csrc/gemm.hip)
-OWN_GEMM = 1          # 1: forward / input-gradient projections of supported shapes run the hand-written persistent 256x256x64 kernel (and
-                      # FeedForward[1] + GEGLU its fused-epilogue form); 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
+OWN_GEMM = 3          # bit 0: forward / input-gradient projections of supported shapes run the hand-written persistent 256x256x64 kernel
+                      # (FeedForward[1] + GEGLU its fused-epilogue form); bit 1: weight gradients its transposing split-K form;
+                      # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
 _OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
 
 
 def own_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     """Can y = x @ w^T run on mmae_gemm_nt?  x (M, K), w (N, K): bf16, unit column stride, 16-byte aligned bases, N % 256 == 0,
     K % 128 == 0, K >= 384, and enough tiles to fill the 256 persistent workgroups."""
-    if not OWN_GEMM or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or not x.is_cuda:
+    if not (OWN_GEMM & 1) or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or not x.is_cuda:
         return False
     M, K = x.shape
     N = w.shape[0]
@@ -213,7 +214,7 @@ def matmul_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 def own_geglu_ok(y: torch.Tensor, w1: torch.Tensor) -> bool:
-    if not OWN_GEMM or y.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or y.dim() != 2 or not y.is_cuda:
+    if not (OWN_GEMM & 1) or y.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or y.dim() != 2 or not y.is_cuda:
         return False
     M, K = y.shape
     F2 = w1.shape[0]
@@ -333,9 +334,31 @@ class _NullCtx:
         return False
 
 
-def _wgrad(g2, x2, gview):
-    """dW = g2^T x2 in fp32 (split-K batched GEMM + sum), written into `gview` when given."""
+def own_wgrad_ok(g2: torch.Tensor, x2: torch.Tensor) -> bool:
+    if not (OWN_GEMM & 2) or g2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or not g2.is_cuda:
+        return False
+    if g2.stride(1) != 1 or x2.stride(1) != 1 or g2.data_ptr() % 16 or x2.data_ptr() % 16:
+        return False
+    return bool(_lib.lib().mmae_gemm_tn_supported(g2.shape[0], g2.shape[1], x2.shape[1], g2.stride(0), x2.stride(0)))
+
+
+def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (N, Kin) fp32 = g2 (rows, N)^T @ x2 (rows, Kin) on the own split-K kernel (csrc/gemm.hip); caller checked own_wgrad_ok."""
     rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
+    out = torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device) if out is None else out
+    assert out.shape == (n_out, n_in) and out.is_contiguous() and out.dtype == torch.float32
+    nws = _lib.lib().mmae_gemm_tn_ws_floats(rows, n_out, n_in)
+    ws = torch.empty(nws, dtype=torch.float32, device=g2.device) if nws else None
+    call("mmae_gemm_tn", rows, n_out, n_in, ptr(g2), g2.stride(0), ptr(x2), x2.stride(0), ptr(out), ptr(ws), stream())
+    return out
+
+
+def _wgrad(g2, x2, gview):
+    """dW = g2^T x2 in fp32, written into `gview` when given: the own transposing split-K kernel where it applies, else a split-K
+    batched library GEMM + sum."""
+    rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
+    if own_wgrad_ok(g2, x2) and (gview is None or (gview.is_contiguous() and gview.data_ptr() % 16 == 0)):
+        return gemm_tn(g2, x2, gview)
     S = _split_k(rows, n_out, n_in)
     if S > 1:
         part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))

@@ -87,3 +87,36 @@ def test_gemm_geglu_matches_separate_path(M, F, K):
     assert float(((g.float() - sep.float()).abs() > 0).float().mean()) < 1e-3     # same formula, same rounding: (almost) bit-identical
     h64 = ref_h.double()
     close(g, O.gelu_erf(h64[:, F:]) * h64[:, :F], 1e-2, "g vs fp64")
+
+
+@pytest.mark.parametrize("rows,N,Kin", [(128, 256, 256), (4096, 512, 256), (10000, 768, 512), (163840, 768, 512), (65536, 4096, 768),
+                                         (40037, 1536, 768), (164096, 1024, 768), (20000, 768, 2048)])
+def test_gemm_tn_weight_gradient_matches_fp32_reference(rows, N, Kin):
+    """dW = G^T X (autograd of nn.Linear): transposing LDS reads, split-K over workgroups, fp32 slabs summed in a fixed order.  Row counts
+    that are not multiples of the 64-row K-tile or of the split size (zero-filled tails), one to 48 output tiles, 1 to 42 splits."""
+    from incomplete_multimodal_fusion_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(rows + N)
+    G = (torch.rand(rows, N, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    X = (torch.rand(rows, Kin, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    assert _lib.lib().mmae_gemm_tn_supported(rows, N, Kin, N, Kin)
+    out = ops.gemm_tn(G, X)
+    ref = G.double().t() @ X.double()
+    close(out, ref, 1e-3, "wgrad %s" % ((rows, N, Kin),))              # fp32 accumulation and output: far inside the bf16 bar
+    assert torch.equal(ops.gemm_tn(G, X), out), "bitwise reproducible"
+    # written in place into a destination view (the optimizer engine's flat gradient buffer)
+    flat = torch.full((N * Kin + 16,), 3.0, device=DEV)
+    view = flat[8:8 + N * Kin].view(N, Kin)
+    if view.data_ptr() % 16 == 0:
+        ops.gemm_tn(G, X, out=view)
+        assert torch.equal(view, out) and float(flat[:8].min()) == 3.0 and float(flat[-8:].min()) == 3.0
+
+
+def test_gemm_tn_strided_operands():
+    from incomplete_multimodal_fusion_amd import ops
+    rows, N, Kin = 9000, 512, 768
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Gw = (torch.rand(rows, 3 * N + 8, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)       # a column block of a fused qkv gradient
+    Xw = (torch.rand(rows, Kin + 40, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    G, X = Gw[:, N:2 * N], Xw[:, :Kin]
+    assert ops.own_wgrad_ok(G, X)
+    close(ops.gemm_tn(G, X), G.double().t() @ X.double(), 1e-3, "strided wgrad")
