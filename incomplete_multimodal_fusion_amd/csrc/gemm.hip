@@ -404,10 +404,16 @@ struct TnLane {
     int lpA, lpB;                    // fragment read bases: (8 g + q) * 512 + 8 p, XORed with 32 m and the wave's column-tile origin
 };
 
-// rows 32 blk .. + 31 of K-tile kt of operand G (which = 0) / X (1) into buffer buf: wave w brings rows 4 w .. 4 w + 3 of the block
-__device__ __forceinline__ void tn_stage(const TnLane& L, int which, int kt, int blk, int buf, int wave) {
-    const int row = 32 * blk + 4 * wave;
-    char* dst = L.lds + buf * 65536 + which * 32768 + row * 512;
+// LDS = a ring of TEN 16 KB slots (all 160 KB of the CU); a staging STEP = 32 rows x 256 columns of one operand (2 DMA per lane), four
+// steps per K-tile in the order G rows 0..31, X rows 0..31, G rows 32..63, X rows 32..63; global step s lives in slot s mod 10.
+// Phase (t, q) issues step 4 t + q + 7: a slot is refilled >= 2 phases after its last read, every read is >= 1 phase after the counted wait
+// that retires its DMA, and FIVE steps (80 KB per CU) stay in flight across the barriers -- the loop is bound by the latency of its
+// operand stream (every tile row is wanted by 3..16 workgroups at the same moment, so all of them see the HBM latency), not by MFMA, LDS or
+// HBM bandwidth: with the two-buffer form of the projection kernel above (3 steps in flight) it ran at 1040 TFLOP/s, with every DMA hitting
+// L2 at 1546.  The slot pattern repeats every 5 K-tiles, so the loop is unrolled by 5 with compile-time LDS addresses.
+//   step kind j = s mod 4: read in phases  j 0: (t,0) (t,1)   j 1: (t,0)   j 2: (t,2) (t,3)   j 3: (t,2)
+__device__ __forceinline__ void tn_stage(const TnLane& L, int which, int kt, int blk, int slot, int wave) {
+    char* dst = L.lds + slot * 16384 + 4 * wave * 512;                  // wave w brings rows 4 w .. 4 w + 3 of the 32-row block
     const int ld2 = which ? L.ldx2 : L.ldg2;
     const int so = (which ? L.sX : L.sG) + (kt * 64 + 32 * blk) * ld2;
     const void* base = which ? (const void*)L.X : (const void*)L.G;
@@ -415,20 +421,24 @@ __device__ __forceinline__ void tn_stage(const TnLane& L, int which, int kt, int
     gm_dma(base, n, which ? L.voffX[0] : L.voffG[0], so, dst);
     gm_dma(base, n, which ? L.voffX[1] : L.voffG[1], so + 2 * ld2, dst + 1024);
 }
+// global step s (any s >= 0) of the K-loop whose first K-tile index is given implicitly: kt = s / 4, kind = s % 4
+template <int KIND>
+__device__ __forceinline__ void tn_stage_step(const TnLane& L, int kt, int slot, int wave) {
+    tn_stage(L, KIND & 1, kt, KIND >> 1, slot, wave);
+}
 
 struct TnFrags { bf16x8 a[4], b[4]; };
 
-// phase (KS, QA): k-step KS (rows 32 KS .. + 31), the wave's n-tiles 4 QA .. + 3 against its 4 kin-tiles
-template <int KS, int QA>
-__device__ __forceinline__ void tn_load(const TnLane& L, int buf, TnFrags& f) {
-    const char* base = L.lds + buf * 65536 + KS * 16384;
+// phase (KS, QA) of the K-tile whose steps sit in slots SA (G rows of k-step KS) / SB (X rows of k-step KS)
+template <int QA, int SA, int SB>
+__device__ __forceinline__ void tn_load(const TnLane& L, TnFrags& f) {
     if (QA == 0) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) f.b[tj] = tn_frag(base + 32768 + (L.lpB ^ (tj * 32)));
+        for (int tj = 0; tj < 4; ++tj) f.b[tj] = tn_frag(L.lds + SB * 16384 + (L.lpB ^ (tj * 32)));
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) f.a[ti] = tn_frag(base + (L.lpA ^ ((4 * QA + ti) * 32)));
+    for (int ti = 0; ti < 4; ++ti) f.a[ti] = tn_frag(L.lds + SA * 16384 + (L.lpA ^ ((4 * QA + ti) * 32)));
 }
 template <int QA>
 __device__ __forceinline__ void tn_mfma(const TnFrags& f, f32x4 (&acc)[8][4]) {
@@ -450,23 +460,24 @@ __device__ __forceinline__ void tn_mfma(const TnFrags& f, f32x4 (&acc)[8][4]) {
     __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);
 
-// K-tile t in buffer b.  Staging order: ... G rows 0..31 of t+2 in phase 3, X rows 0..31 of t+1 in phase 0, G rows 32..63 of t+1 in phase 1,
-// X rows 32..63 of t+1 in phase 2: a block is restaged >= 2 phases after its last read; the waits (phase 1: rows 32..63 of THIS K-tile,
-// phase 3: rows 0..31 of the next) leave 3 staging steps = 6 DMA in flight.  K-tiles beyond the split's last row stage zeros (range check).
-__device__ __forceinline__ void tn_ktile(const TnLane& L, int t, int b, int wave, TnFrags& f, f32x4 (&acc)[8][4]) {
-    tn_load<0, 0>(L, b, f);
-    tn_stage(L, 1, t + 1, 0, b ^ 1, wave);
+// K-tile t with t mod 5 == R: its steps 4 t .. 4 t + 3 sit in slots (4 R + j) mod 10; phase q issues step 4 t + q + 7 into slot (4 R + q + 7) mod 10
+// (kinds 3, 0, 1, 2 of K-tiles t+1, t+2, t+2, t+2).  Waits in phases 1 and 3: vmcnt(10) = five steps stay in flight.
+template <int R>
+__device__ __forceinline__ void tn_ktile(const TnLane& L, int t, int wave, TnFrags& f, f32x4 (&acc)[8][4]) {
+    constexpr int S0 = (4 * R) % 10, S1 = (4 * R + 1) % 10, S2 = (4 * R + 2) % 10, S3 = (4 * R + 3) % 10;
+    tn_load<0, S0, S1>(L, f);
+    tn_stage_step<3>(L, t + 1, (4 * R + 7) % 10, wave);
     TN_PHASE_TAIL(0)
-    tn_load<0, 1>(L, b, f);
-    tn_stage(L, 0, t + 1, 1, b ^ 1, wave);
-    GM_VMCNT(6);
+    tn_load<1, S0, S1>(L, f);
+    tn_stage_step<0>(L, t + 2, (4 * R + 8) % 10, wave);
+    GM_VMCNT(10);
     TN_PHASE_TAIL(1)
-    tn_load<1, 0>(L, b, f);
-    tn_stage(L, 1, t + 1, 1, b ^ 1, wave);
+    tn_load<0, S2, S3>(L, f);
+    tn_stage_step<1>(L, t + 2, (4 * R + 9) % 10, wave);
     TN_PHASE_TAIL(0)
-    tn_load<1, 1>(L, b, f);
-    tn_stage(L, 0, t + 2, 0, b, wave);
-    GM_VMCNT(6);
+    tn_load<1, S2, S3>(L, f);
+    tn_stage_step<2>(L, t + 2, (4 * R + 10) % 10, wave);
+    GM_VMCNT(10);
     TN_PHASE_TAIL(1)
 }
 
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs p) {
     const int split = lin / p.T, tile = lin - split * p.T;
     const int tn = tile / p.tkin, tk = tile - tn * p.tkin;
     const int r_begin = split * p.rows_per_split, r_end = min(p.rows, r_begin + p.rows_per_split);
-    const int NT = ((r_end - r_begin + 127) >> 7) << 1;                  // K-tiles of 64 rows, rounded up to even (the tail stages zeros)
+    const int NT5 = (r_end - r_begin + 319) / 320;                       // groups of 5 K-tiles of 64 rows (rows beyond r_end stage zeros)
     TnLane L;
     L.lds = lds; L.G = p.G; L.X = p.X;
     L.ldg2 = p.ldg * 2; L.ldx2 = p.ldx * 2;
@@ -497,8 +508,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs p) {
         const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
         const int m = qq | ((g & 1) << 2);
         const int lp = (8 * g + qq) * 512 + 8 * pp;
-        L.lpA = lp ^ (32 * m) ^ (256 * wr);                               // n-tiles 8 wr .. of the G tile
-        L.lpB = lp ^ (32 * m) ^ (128 * wc);                               // kin-tiles 4 wc .. of the X tile
+        L.lpA = lp ^ (32 * m) ^ (256 * wr);                               // n-tiles 8 wr .. of the G block
+        L.lpB = lp ^ (32 * m) ^ (128 * wc);                               // kin-tiles 4 wc .. of the X block
     }
     f32x4 acc[8][4];
 #pragma unroll
@@ -506,17 +517,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     TnFrags f;
-    tn_stage(L, 0, 0, 0, 0, wave); tn_stage(L, 1, 0, 0, 0, wave); tn_stage(L, 0, 0, 1, 0, wave); tn_stage(L, 1, 0, 1, 0, wave);
-    tn_stage(L, 0, 1, 0, 1, wave);
-    GM_VMCNT(6);
+    // prologue: steps 0 .. 6 (K-tile 0 complete, K-tile 1 up to its G rows 32..63) into slots 0 .. 6; steps 0, 1 landed before phase 0
+    tn_stage_step<0>(L, 0, 0, wave); tn_stage_step<1>(L, 0, 1, wave); tn_stage_step<2>(L, 0, 2, wave); tn_stage_step<3>(L, 0, 3, wave);
+    tn_stage_step<0>(L, 1, 4, wave); tn_stage_step<1>(L, 1, 5, wave); tn_stage_step<2>(L, 1, 6, wave);
+    GM_VMCNT(10);
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < NT; t += 2) {
-        tn_ktile(L, t, 0, wave, f, acc);
-        tn_ktile(L, t + 1, 1, wave, f, acc);
+    if (wr == 1) __builtin_amdgcn_s_barrier();                           // waves 4..7 run one barrier behind
+    for (int t5 = 0; t5 < NT5; ++t5) {
+        const int t = 5 * t5;
+        tn_ktile<0>(L, t, wave, f, acc);
+        tn_ktile<1>(L, t + 1, wave, f, acc);
+        tn_ktile<2>(L, t + 2, wave, f, acc);
+        tn_ktile<3>(L, t + 3, wave, f, acc);
+        tn_ktile<4>(L, t + 4, wave, f, acc);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    GM_VMCNT(0);                                                          // the zero-fill staging of the (non-existent) K-tiles NT, NT + 1
+    GM_VMCNT(0);                                                          // the zero-fill staging of the K-tiles beyond the last one
     // acc[it][jt][reg] = dW[tn 256 + 128 wr + 16 it + 4 g + reg][tk 256 + 64 wc + 16 jt + (lane & 15)]: once per workgroup
     float* out = p.P + (long)split * p.N * p.Kin + ((long)tn * 256 + 128 * wr + 4 * (lane >> 4)) * p.Kin + tk * 256 + 64 * wc + (lane & 15);
 #pragma unroll
@@ -570,14 +586,14 @@ extern "C" int mmae_gemm_tn(long rows, long N, long Kin, const void* G, long ldg
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_tn8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return MMAE_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)gemm_tn8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return MMAE_ERR_LAUNCH;
         attr_set = true;
     }
     TnArgs a{};
     a.G = (const bf16*)G; a.X = (const bf16*)X; a.P = pl.S > 1 ? ws : out;
     a.rows = (int)rows; a.N = (int)N; a.Kin = (int)Kin; a.ldg = (int)ldg; a.ldx = (int)ldx;
     a.tkin = pl.tkin; a.T = pl.T; a.S = pl.S; a.rows_per_split = pl.rps;
-    MMAE_LAUNCH(gemm_tn8p_kernel, dim3(pl.T * pl.S), dim3(512), 131072, st, a);
+    MMAE_LAUNCH(gemm_tn8p_kernel, dim3(pl.T * pl.S), dim3(512), 163840, st, a);
     MMAE_CHECK_LAUNCH();
     if (pl.S > 1) {
         const long n = N * Kin;

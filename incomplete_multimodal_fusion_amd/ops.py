@@ -174,8 +174,12 @@ def join_wgrad_stream():
 
 
 # ------------------------------------------------------------------------------------------------ own GEMM (csrc/gemm.hip)
-OWN_GEMM = 3          # bit 0: forward / input-gradient projections of supported shapes run the hand-written persistent 256x256x64 kernel
-                      # (FeedForward[1] + GEGLU its fused-epilogue form); bit 1: weight gradients its transposing split-K form;
+OWN_GEMM = 1          # bit 0: forward / input-gradient projections of supported shapes run the hand-written persistent 256x256x64 kernel
+                      # (FeedForward[1] + GEGLU its fused-epilogue form): faster than the tuned library GEMM on 16 of 17 shapes
+                      # (tools/bench_gemm.py), -1.9 ms per step.  bit 1: weight gradients on its transposing split-K form (mmae_gemm_tn):
+                      # correct and tested, but 5-30 % SLOWER than the library's split-K batched GEMM (tools/bench_wgrad.py; the loop is
+                      # bound by the latency of its operand stream: 1546 TFLOP/s with every DMA hitting L2, 1040 from HBM at a 75 % L2 hit
+                      # rate, no change from 3 to 5 staging steps in flight), +4.7 ms in the step -> OFF by default.
                       # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
 _OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
 
