@@ -24,7 +24,7 @@ extern "C" {
 #define MMAE_BF16 1
 #define MMAE_ABI_VERSION 4   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
                                 mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
-                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn */
+                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn, mmae_splitk_sum_multi */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -208,6 +208,9 @@ int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16, const void
 /* out[i] = sum_s partials[s*n + i], fp32 accumulation in fixed order: reduction of the S bf16 partial products of a split-K
  * weight-gradient GEMM (autograd of nn.Linear in the reference) into its fp32 destination.  n % 8 == 0. */
 int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* stream);
+/* The same for `count` gradients in one launch per 16 (host arrays of count device pointers / sizes; bitwise identical to count calls of
+ * mmae_splitk_sum): a layer's weight gradients are summed together when its backward has run. */
+int mmae_splitk_sum_multi(int count, const void* const* partials_bf16, float* const* outs, const int* S, const long* n, void* stream);
 /* L2 norm of a flat fp32 gradient buffer (deterministic two-stage sum); partial_ws: 2048 floats. */
 int mmae_grad_norm(long n, const float* g, float* partial_ws_2048, float* out_norm, void* stream);
 

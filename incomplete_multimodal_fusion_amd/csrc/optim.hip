@@ -121,6 +121,37 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const bf16* __restrict_
     *reinterpret_cast<f32x4*>(out + i + 4) = b;
 }
 
+// The same for up to 16 weight gradients in ONE launch (a layer's worth: the per-gradient launches were ~140 dependent 6-us kernels per
+// step): the entries travel by value in the kernel argument (no pointer table in memory, no host-to-device copy); block b serves the
+// entry e with first_block[e] <= b < first_block[e + 1].  Same summation order as splitk_sum_kernel: bitwise identical results.
+struct SplitkMulti {
+    const bf16* part[16]; float* out[16]; long n[16]; int S[16]; int first_block[17]; int count;
+};
+__global__ __launch_bounds__(256) void splitk_sum_multi_kernel(SplitkMulti m) {
+    int e = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) e += (k < m.count && (int)blockIdx.x >= m.first_block[k]) ? 1 : 0;
+    const long n = m.n[e];
+    const long i = ((long)(blockIdx.x - m.first_block[e]) * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const bf16* part = m.part[e];
+    const int S = m.S[e];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) {
+        union { uint4 q; bf16 e[8]; } v;
+        v.q = *reinterpret_cast<const uint4*>(part + (long)s * n + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+    }
+    f32x4 a, b;
+    a[0] = acc[0]; a[1] = acc[1]; a[2] = acc[2]; a[3] = acc[3];
+    b[0] = acc[4]; b[1] = acc[5]; b[2] = acc[6]; b[3] = acc[7];
+    float* out = m.out[e];
+    *reinterpret_cast<f32x4*>(out + i) = a;
+    *reinterpret_cast<f32x4*>(out + i + 4) = b;
+}
+
 // sum of squares of a flat fp32 buffer -> out[0] (+= when accumulate): two-stage, deterministic
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
     __shared__ float red[4];
@@ -207,6 +238,27 @@ extern "C" int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* 
     MMAE_LAUNCH(splitk_sum_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(partials_bf16), S, n, out);
     MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_splitk_sum_multi(int count, const void* const* partials_bf16, float* const* outs, const int* S, const long* n, void* stream) {
+    if (count < 0 || (count > 0 && (!partials_bf16 || !outs || !S || !n))) return MMAE_ERR_ARG;
+    for (int i = 0; i < count; ++i)
+        if (!partials_bf16[i] || !outs[i] || S[i] < 1 || n[i] <= 0 || (n[i] % 8)) return MMAE_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < count; base += 16) {
+        SplitkMulti m{};
+        m.count = count - base < 16 ? count - base : 16;
+        int blocks = 0;
+        for (int k = 0; k < m.count; ++k) {
+            m.part[k] = reinterpret_cast<const bf16*>(partials_bf16[base + k]); m.out[k] = outs[base + k];
+            m.n[k] = n[base + k]; m.S[k] = S[base + k]; m.first_block[k] = blocks;
+            blocks += (int)((n[base + k] / 8 + 255) / 256);
+        }
+        m.first_block[m.count] = blocks;
+        MMAE_LAUNCH(splitk_sum_multi_kernel, dim3(blocks), dim3(256), 0, st, m);
+        MMAE_CHECK_LAUNCH();
+    }
     return MMAE_OK;
 }
 

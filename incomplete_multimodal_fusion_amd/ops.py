@@ -296,10 +296,11 @@ class _Linear(torch.autograd.Function):
                 if use_side:
                     ss.wait_stream(main)
                     g2.record_stream(ss); x2.record_stream(ss)
+                publish = ctx.gview is not None and all(ctx.needs_input_grad[3:])
                 with torch.cuda.stream(ss) if use_side else _NullCtx():
-                    gw = _wgrad(g2, x2, ctx.gview)   # ctx.gview: flat fp32 gradient buffer of the optimizer engine (or None)
+                    # ctx.gview: flat fp32 gradient buffer of the optimizer engine (or None); published by _wgrad when it is the destination
+                    gw = _wgrad(g2, x2, ctx.gview, ctx.ws if publish else None)
                     off = 0
-                    publish = ctx.gview is not None and all(ctx.needs_input_grad[3:])
                     for i, n in enumerate([] if publish else sizes):
                         if ctx.needs_input_grad[3 + i]:
                             gi = gw[off:off + n]
@@ -307,9 +308,6 @@ class _Linear(torch.autograd.Function):
                             if use_side:
                                 gws[i].record_stream(main)
                         off += n
-                if publish:
-                    from .engine import grads_written_in_place
-                    grads_written_in_place(ctx.ws)           # .grad = flat view; autograd gets None (no clone, no copy back)
             gb = None
             if bdt is not False and ctx.needs_input_grad[1]:
                 gb = colsum(g2)
@@ -357,22 +355,70 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
-def _wgrad(g2, x2, gview):
+# Split-K sums of weight gradients that go straight into the optimizer engine's flat buffer are DEFERRED: the partial products are kept
+# and a layer's worth of sums runs as ONE multi-tensor launch (mmae_splitk_sum_multi) -- when the layer's backward has run
+# (_KvQ.backward, the last projection of a layer) and, for whatever is left, when the backward pass ends (autograd engine callback).
+# The gradient is PUBLISHED (engine.grads_written_in_place: .grad set, DP reducer told) by the flush, after the launch that completes it,
+# so its only consumers -- optimizer step and gradient all-reduce -- stay ordered behind it on the stream.  ~140 dependent 6-us launches
+# per step become ~15.  (A gradient that autograd itself consumes is never deferred: its consumer kernel is enqueued at once.)
+DEFER_SPLITK = True
+_SPLITK_Q = []                 # (partials, S, n, out view, weights to publish)
+_SPLITK_CB = [False]
+
+
+def flush_splitk():
+    """Run the queued split-K sums (one launch per 16) and publish their gradients.  Safe to call at any time."""
+    if not _SPLITK_Q:
+        return
+    q = list(_SPLITK_Q)
+    _SPLITK_Q.clear()
+    n = len(q)
+    parts = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in q])
+    outs = (ctypes.c_void_p * n)(*[e[3].data_ptr() for e in q])
+    Ss = (ctypes.c_int * n)(*[e[1] for e in q])
+    ns = (ctypes.c_long * n)(*[e[2] for e in q])
+    call("mmae_splitk_sum_multi", n, ctypes.cast(parts, ctypes.c_void_p), ctypes.cast(outs, ctypes.c_void_p),
+         ctypes.cast(Ss, ctypes.c_void_p), ctypes.cast(ns, ctypes.c_void_p), stream())
+    from .engine import grads_written_in_place
+    for e in q:
+        if e[4] is not None:
+            grads_written_in_place(e[4])
+
+
+def _end_of_backward_flush():
+    _SPLITK_CB[0] = False
+    flush_splitk()
+
+
+def _wgrad(g2, x2, gview, publish=None):
     """dW = g2^T x2 in fp32, written into `gview` when given: the own transposing split-K kernel where it applies, else a split-K
-    batched library GEMM + sum."""
+    batched library GEMM + sum.  publish: the weights whose in-place gradient this is -- the call then publishes it itself
+    (engine.grads_written_in_place), at once or, for a deferred split-K sum, at the flush; the caller must not."""
     rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
+
+    def done(out):
+        if publish is not None:
+            from .engine import grads_written_in_place
+            grads_written_in_place(publish)
+        return out
     if own_wgrad_ok(g2, x2) and (gview is None or (gview.is_contiguous() and gview.data_ptr() % 16 == 0)):
-        return gemm_tn(g2, x2, gview)
+        return done(gemm_tn(g2, x2, gview))
     S = _split_k(rows, n_out, n_in)
     if S > 1:
         part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
         if part.dtype == torch.bfloat16 and (n_out * n_in) % 8 == 0:
             out = gview if gview is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device)
+            if publish is not None and gview is not None and DEFER_SPLITK and torch.cuda.current_stream() == torch.cuda.default_stream():
+                _SPLITK_Q.append((part, S, n_out * n_in, out, publish))
+                if not _SPLITK_CB[0]:
+                    _SPLITK_CB[0] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_flush)
+                return out
             call("mmae_splitk_sum", S, n_out * n_in, ptr(part), ptr(out), stream())
-            return out
-        return torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else part.sum(0, dtype=torch.float32)
+            return done(out)
+        return done(torch.sum(part, 0, dtype=torch.float32, out=gview) if gview is not None else part.sum(0, dtype=torch.float32))
     gw = torch.mm(g2.t(), x2)
-    return gview.copy_(gw) if gview is not None else gw.float()
+    return done(gview.copy_(gw) if gview is not None else gw.float())
 
 
 class _KvQ(torch.autograd.Function):
@@ -409,11 +455,11 @@ class _KvQ(torch.autograd.Function):
             gz = matmul_nt(gkv, wt if wt is not None else wkv_c.t().contiguous())
             zs = gz[r0:r0 + n]
             torch.addmm(zs, gq, wq_c, out=zs)
-            gwkv = _wgrad(gkv, z, gvkv)
-            gwq = _wgrad(gq, z[r0:r0 + n], gvq)
-        if gvq is not None and gvkv is not None:
-            from .engine import grads_written_in_place
-            grads_written_in_place((ctx.wq, ctx.wkv))
+            both = gvq is not None and gvkv is not None
+            gwkv = _wgrad(gkv, z, gvkv, (ctx.wkv,) if both else None)
+            gwq = _wgrad(gq, z[r0:r0 + n], gvq, (ctx.wq,) if both else None)
+        if both:
+            flush_splitk()            # the last projections of a layer in backward order: this layer's deferred split-K sums in one launch
             return gz, None, None, None, None
         return gz, None, None, gwq if gwq.dtype == dq_ else gwq.to(dq_), gwkv if gwkv.dtype == dkv_ else gwkv.to(dkv_)
 
@@ -470,7 +516,7 @@ class _KvCtx(torch.autograd.Function):
             need_kv = ctx.needs_input_grad[3]                      # a frozen weight gets no gradient (and no flat-buffer write)
             need_w = [ctx.needs_input_grad[5 + i] for i in range(nw)]
             need_b = [ctx.needs_input_grad[5 + nw + i] for i in range(len(bdt))]
-            gwkv = _wgrad(gkv, z, gvkv) if need_kv else None
+            gwkv = _wgrad(gkv, z, gvkv, (ctx.wkv,) if gvkv is not None else None) if need_kv else None
             gwc = _wgrad(gc, z[r0:r0 + n], None) if any(need_w) else None
             gb = colsum(gc) if (bdt and any(need_b)) else None
         gws, gbs, off = [], [], 0
@@ -484,9 +530,7 @@ class _KvCtx(torch.autograd.Function):
             gbs.append(g if (g is None or g.dtype == dt_) else g.to(dt_))
             off += sz
         if need_kv and gvkv is not None:
-            from .engine import grads_written_in_place
-            grads_written_in_place((ctx.wkv,))
-            gwkv = None
+            gwkv = None                                     # published by _wgrad (in place in the engine's flat buffer)
         elif gwkv is not None and gwkv.dtype != dkv_:
             gwkv = gwkv.to(dkv_)
         return (gz, None, None, gwkv, None, *gws, *gbs)
@@ -1018,11 +1062,10 @@ class _FeedForwardGEGLU(torch.autograd.Function):
                 call("mmae_geglu_bwd", dt(T), b - a, F, ptr(h[a:b]), ptr(dg), ptr(dh[a:b]), stream())
                 if dy is not None:
                     matmul_nt(dh[a:b], w1t, out=dy[a:b])                  # dy = dh @ W1
-            gw2 = _wgrad(df, g, gv2)
-            gw1 = _wgrad(dh, y, gv1)
-        if gv1 is not None and gv2 is not None:
-            from .engine import grads_written_in_place
-            grads_written_in_place((w1, w2))
+            both = gv1 is not None and gv2 is not None
+            gw2 = _wgrad(df, g, gv2, (w2,) if both else None)
+            gw1 = _wgrad(dh, y, gv1, (w1,) if both else None)
+        if both:
             return dy, None, None
         return dy, gw1 if gw1.dtype == w1.dtype else gw1.to(w1.dtype), gw2 if gw2.dtype == w2.dtype else gw2.to(w2.dtype)
 

@@ -9,7 +9,8 @@ The product package reads NO tuning variable itself (only MMAE_HIP_LIB, the libr
     MMAE_DUAL_LN         multimae_crossattn.DUAL_LAYERNORM
     MMAE_DECODER_STREAMS multimae_crossattn.DECODER_STREAMS
     MMAE_SPLITK_CAP / MMAE_SPLITK_MAX / MMAE_WGRAD_PRIO / MMAE_FF_CHUNKS      the ops.py constants of the same names
-    MMAE_OWN_GEMM        ops.OWN_GEMM               0: library GEMMs for the feed-forward, 1: the own 8-phase GEMM with fused epilogues
+    MMAE_OWN_GEMM        ops.OWN_GEMM               bit 0: own 8-phase GEMM for forward / input-gradient projections, bit 1: for weight gradients
+    MMAE_DEFER_SPLITK    ops.DEFER_SPLITK           0: one split-K sum launch per weight gradient instead of one per layer
 """
 import os
 
@@ -31,6 +32,7 @@ def apply(verbose=True):
     put(ops, "WGRAD_STREAM_PRIORITY", "MMAE_WGRAD_PRIO", int)
     put(ops, "FF_CHUNKS", "MMAE_FF_CHUNKS", int)
     put(ops, "OWN_GEMM", "MMAE_OWN_GEMM", int)
+    put(ops, "DEFER_SPLITK", "MMAE_DEFER_SPLITK", flag)
     put(mc, "FUSED_FINAL_CAST", "MMAE_FUSED_CAST", flag)
     put(mc, "FUSED_DECODER_CTX", "MMAE_FUSED_CTX", flag)
     put(mc, "DUAL_LAYERNORM", "MMAE_DUAL_LN", flag)
