@@ -502,6 +502,15 @@ __device__ __forceinline__ float wave_sum_v(float v) {
     return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
+// EXPERIMENT knob: the normalised output is the next GEMM's operand -- nontemporal (streaming) or regular stores?
+#ifndef MMAE_Y_NT
+#define MMAE_Y_NT 1
+#endif
+#if MMAE_Y_NT
+#define STY st4s
+#else
+#define STY st4f
+#endif
 template <typename TD, typename TY, int NC, bool DOUBLE, bool HAS_DELTA, bool Y2 = false>
 __global__ __launch_bounds__(256) void add_ln_fwd_fast_kernel(AddLnFwd p) {
     const int lane = threadIdx.x & 63;
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_fast_kernel(AddLnFwd p) {
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        st4s<TY>(reinterpret_cast<TY*>(p.y) + at + 256 * c, v[c]);
+        STY<TY>(reinterpret_cast<TY*>(p.y) + at + 256 * c, v[c]);
         if (Y2) st4s<bf16>(reinterpret_cast<bf16*>(p.y2) + at + 256 * c, v[c]);
     }
     if (lane == 0) *reinterpret_cast<f32x4*>(p.stats + row * 4) = f32x4{m1, r1, m2, r2};
@@ -677,8 +686,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_dual_fast_kernel(AddLnFwdDual 
     const float r2a = rsqrtf(wave_sum_v(q2[0]) * invD + p.eps2), r2b = rsqrtf(wave_sum_v(q2[1]) * invD + p.eps2);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        st4s<TY>(reinterpret_cast<TY*>(p.ya) + at + 256 * c, u[0][c] * r2a * G2[0][c]);
-        st4s<TY>(reinterpret_cast<TY*>(p.yb) + at + 256 * c, u[1][c] * r2b * G2[1][c]);
+        STY<TY>(reinterpret_cast<TY*>(p.ya) + at + 256 * c, u[0][c] * r2a * G2[0][c]);
+        STY<TY>(reinterpret_cast<TY*>(p.yb) + at + 256 * c, u[1][c] * r2b * G2[1][c]);
     }
     if (lane == 0) {
         *reinterpret_cast<f32x4*>(p.stats_a + row * 4) = f32x4{m1, r1, m2a, r2a};
