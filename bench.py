@@ -199,7 +199,7 @@ def gemm_roofline():
     the counters cannot be collected in-process); None when absent."""
     js, rnd = _profile_json("sq_step")
     try:
-        ks = {n: k for n, k in js["kernels"].items() if n.startswith(("Cijk", "Custom_Cijk"))}
+        ks = {n: k for n, k in js["kernels"].items() if n.startswith(("Cijk", "Custom_Cijk")) or "gemm8p_kernel" in n or "gemm_tn8p" in n}
         name, top = max(ks.items(), key=lambda kv: kv[1]["ms"])
         steps, step_ms = js["step"]["steps"], js["step"]["kernel_ms_per_step"]
         gemm_ms = sum(k["ms"] for k in ks.values())
@@ -523,9 +523,11 @@ def main():
 
     prof = ops.KernelTimer("mmae_mha_fwd")
     prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
+    prof_gemm = ops.KernelTimer("mmae_gemm_nt")
+    prof_gemm.every = 7                       # 182 launches per step: every 7th is bracketed (26 per step, all shapes in rotation)
     for _ in range(args.warmup):
         losses = step(x)
-    ops.set_kernel_timer([prof, prof_ln])
+    ops.set_kernel_timer([prof, prof_ln, prof_gemm])
     # roofline_block: HIP events around ONE encoder layer (Block_Fusion + Block) of the middle of the stack, forward and backward
     block_layer = min(6, model.depth - 1)
     model.layer_timer = ops.LayerTimer(block_layer) if (model.depth > 1 and args.block_timer) else None
@@ -641,6 +643,17 @@ def main():
                                      "achieved": round(ach_b, 1), "frac": round(ach_b / MFMA_BF16_PEAK_TF, 4),
                                      "achieved_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12, 1) if tot_ms > 0 else 0.0,
                                      "frac_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if tot_ms > 0 else 0.0}
+        # the dominant kernel of the step BY TIME: the own persistent GEMM (csrc/gemm.hip, gemm8p_kernel<0>: every forward / input-gradient
+        # projection of the encoder), measured live -- HIP events around every 7th launch on the stream it runs on, 2 M N K FLOPs each
+        g_raw, g_n, g_fl = prof_gemm.summary()
+        if g_n:
+            g_ms = max(g_raw - ev_ms, 1e-6)
+            g_tf = g_fl / g_n / (g_ms * 1e-3) / 1e12
+            out["roofline_gemm_own"] = {"kernel": "gemm8p_kernel<0> (own persistent 256x256x64 8-phase GEMM: forward + input-gradient projections)",
+                                        "bound": "mfma", "achieved": round(g_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                        "frac": round(g_tf / MFMA_BF16_PEAK_TF, 4), "avg_launch_ms": round(g_ms, 4),
+                                        "avg_flops_per_launch": round(g_fl / g_n), "bracketed_launches": g_n,
+                                        "sampling": "every 7th launch of mmae_gemm_nt", "event_bracket_overhead_ms": round(ev_ms, 4)}
         if replay_ok:
             # replayed (not measured in this process): null when the profiled step no longer matches this run
             rg = gemm_roofline()
