@@ -41,8 +41,11 @@ def timed(fn, it=10, rounds=3):
     return best * 1e3
 
 
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 rows = []
 for name, M, N, K in SHAPES:
+    if only and only not in name:
+        continue
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -58,6 +61,8 @@ for name, M, N, K in SHAPES:
     print("%-24s M %6d N %4d K %4d   library %7.1f us (%4.0f TF)   own %7.1f us (%4.0f TF)   own/lib %.3f" %
           (name, M, N, K, min(tl), fl / min(tl) / 1e6, min(to), fl / min(to) / 1e6, min(to) / min(tl)), flush=True)
 for name, M, F, K in GEGLU:
+    if only and only not in name:
+        continue
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(2 * F, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     h = torch.empty(M, 2 * F, device="cuda", dtype=torch.bfloat16); g = torch.empty(M, F, device="cuda", dtype=torch.bfloat16)
