@@ -608,7 +608,7 @@ def main():
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n},
             # the flagship MFMA kernel of the path (north_star: fusion-attention block), mask-aware algorithmic FLOPs
-            "roofline_attention": {"kernel": "mha_sh_fwd_kernel<0>" if not args.fp32 else "mha_fwd_kernel<float, 64>",
+            "roofline_attention": {"kernel": "+".join(sorted(prof.kernels)) or None,   # as routed by the library (mmae_mha_fwd_route)
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
                          "traffic": pmc_traffic("mha_sh_fwd") if (replay_ok and hbm_ok) else None,

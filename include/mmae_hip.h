@@ -41,6 +41,9 @@ int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
                  float* lse, long q_stride, long k_stride, long v_stride, long o_stride, long q_rows_total,
                  const int* q_seg_start, const int* q_seg_len, const int* k_seg_start, const int* k_seg_len,
                  int max_q_rows, int max_k_rows, float scale, int empty_mode, void* stream);
+/* which forward kernel mmae_mha_fwd launches for these arguments: 0 the fp32 kernel, 1 the bf16 tile-per-block kernel, 2 the bf16
+ * sample-head kernel (mha_sh_fwd_kernel).  A query (no launch): bench.py labels its attention roofline with it. */
+int mmae_mha_fwd_route(int dtype, int head_dim, int nseg, int max_q_rows, int max_k_rows, long k_stride, long v_stride);
 /* backward of the above (autograd of the same lines).  delta_ws: mmae_mha_bwd_ws_floats(H, q_rows_total) fp32 scratch -- three
  * (H, q_rows_total) planes: delta and the row constants handed from the dQ kernel to the dK/dV kernel (ABI 3; ABI 2 took ONE plane:
  * an old-size buffer is a device out-of-bounds write, the library cannot check it -- size it with the function). */

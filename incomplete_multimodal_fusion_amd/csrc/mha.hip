@@ -479,6 +479,15 @@ extern "C" int mmae_mha_fwd(int dtype, int head_dim, int B, int H, int nseg, con
                                 empty_mode, 0, stream);
 }
 
+extern "C" int mmae_mha_fwd_route(int dtype, int head_dim, int nseg, int max_q_rows, int max_k_rows, long k_stride, long v_stride) {
+    if ((dtype != MMAE_F32 && dtype != MMAE_BF16) || (head_dim != 32 && head_dim != 64) || nseg <= 0 || nseg > MAXSEG ||
+        max_q_rows < 0 || max_k_rows < 0) return MMAE_ERR_ARG;
+    if (dtype == MMAE_F32) return 0;
+    MhaDesc d{};
+    d.nseg = nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows; d.k_stride = k_stride; d.v_stride = v_stride;
+    return (head_dim == 64 && mha_sh_applicable(d)) ? 2 : 1;   // the same test mha_bf16_fwd() routes the default variant by
+}
+
 extern "C" long mmae_mha_bwd_ws_floats(int H, long q_rows_total) {
     return (H <= 0 || q_rows_total <= 0) ? MMAE_ERR_ARG : 3L * H * q_rows_total;
 }

@@ -242,7 +242,7 @@ extern "C" int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* 
 }
 
 extern "C" int mmae_splitk_sum_multi(int count, const void* const* partials_bf16, float* const* outs, const int* S, const long* n, void* stream) {
-    if (count < 0 || (count > 0 && (!partials_bf16 || !outs || !S || !n))) return MMAE_ERR_ARG;
+    if (count < 0 || !partials_bf16 || !outs || !S || !n) return MMAE_ERR_ARG;
     for (int i = 0; i < count; ++i)
         if (!partials_bf16[i] || !outs[i] || S[i] < 1 || n[i] <= 0 || (n[i] % 8)) return MMAE_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -140,7 +140,7 @@ class GradAllReducer:
     def _launch(self, b: _Bucket):
         if self.engine is not None:
             self.engine.flush()                              # batched copy of the small gradients into the flat buffer
-        self._sent_bytes += b.flat.numel() * (2 if self.grad_dtype == torch.bfloat16 else 4)
+        self._sent_bytes += b.flat.numel() * torch.empty((), dtype=self.grad_dtype).element_size()
         self._sent_buckets += 1
         if self.world > 1:
             # RCCL averages inside the collective (ncclAvg); gloo has no AVG, finish() scales there

@@ -416,7 +416,8 @@ class MultiMAE(nn.Module):
         if self.output_adapters is not None and self.has_contrastive_tokens:
             # the contrastive queries' keys (:530-543) are a row gather of kvp; taken here, in one node with the pass-through that
             # the pooling attention reads, so that kvp's two gradients are merged by a scatter-add instead of a full-size sum
-            kvp, gk = ops.fork_gather_rows(kvp, desc.tok_fus, filt=desc.tok_mod, nfilt=M)                  # (B*N, 2I)
+            # (its one consumer below, ops.mha_cross, returns a gradient tensor it allocates itself: fresh_grad)
+            kvp, gk = ops.fork_gather_rows(kvp, desc.tok_fus, filt=desc.tok_mod, nfilt=M, fresh_grad=True)   # (B*N, 2I)
         rq = linear(ops.layernorm(self.return_tokens[0].contiguous(), ap.norm.gamma, out_dtype=T), ap.to_q.weight)
         a = ops.mha_cross(rq.repeat(B, 1), kvp, Hh, dh, desc.pool_q, desc.enc_seg, ap.scale, empty_mode=0)
         pooled = linear(a, ap.to_out.weight).float()                                        # (B*R, D)

@@ -28,7 +28,7 @@ class KernelTimer:
     `flops` accumulates the algorithmic work of the timed launches (FLOPs or bytes, a device scalar or a python number)."""
 
     def __init__(self, name: str):
-        self.name, self.pairs, self.flops = name, [], None
+        self.name, self.pairs, self.flops, self.kernels = name, [], None, set()      # kernels: device kernel names the launches ran
 
     def bracket(self):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -607,6 +607,17 @@ def linear(x, weight, bias=None, side_wgrad=False, once=False):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+MHA_ROUTES = {0: "mha_fwd_kernel<float>", 1: "mha_bf16_fwd32_kernel", 2: "mha_sh_fwd_kernel"}
+
+
+def mha_fwd_route(dtype, dh, qseg, kseg, kv_stride):
+    """Which forward kernel mmae_mha_fwd launches for this call (keys of MHA_ROUTES) -- the library's own routing test."""
+    r = _lib.lib().mmae_mha_fwd_route(1 if dtype == torch.bfloat16 else 0, dh, qseg.nseg, qseg.max_rows, kseg.max_rows, kv_stride, kv_stride)
+    if r < 0:
+        raise _lib.MmaeLibraryError("mmae_mha_fwd_route: bad arguments")
+    return r
+
+
 class _MHA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qt, kvt, qcol, kcol, vcol, H, dh, qseg, kseg, scale, empty_mode, variant=0):
@@ -623,10 +634,14 @@ class _MHA(torch.autograd.Function):
                                         "(MAXT in csrc/mha_bf16.hip); got %d query / %d key rows" % (qseg.max_rows, kseg.max_rows))
         es = qt.element_size()
         # bench.py's roofline_attention: every launch that the library routes to the sample-head forward kernel (encoder
-        # blocks: >= 128 rows per sample; the few-query pooling calls run the tile-per-block kernel), so the event average
-        # is the same population as mha_sh_fwd_kernel's row in the rocprofv3 summary
-        timed = _TIMER is not None and _TIMER.name == "mmae_mha_fwd" and dh == 64 and qseg.max_rows >= 128 and kseg.max_rows >= 128
+        # blocks; the few-query pooling calls run the tile-per-block kernel) -- asked of the library itself
+        # (mmae_mha_fwd_route), so the event average is the same population as mha_sh_fwd_kernel's row in the rocprofv3 summary
+        timed = False
+        if _TIMER is not None and not variant and dh == 64:
+            route = mha_fwd_route(qt.dtype, dh, qseg, kseg, kv.stride(0))
+            timed = route == 2 or (route == 0 and qseg.max_rows >= 128 and kseg.max_rows >= 128)    # fp32: the same calls
         if timed:
+            _TIMER.kernels.add(MHA_ROUTES[route])
             ql, kl = qseg.length.long(), kseg.length.long()
             pairs = (ql[:, :-1] * kl[:, :-1]).sum() + (ql[:, -1] * kl.sum(1)).sum()     # mask-aware (q, k) pairs
             _TIMER.add_flops(pairs.double() * (4.0 * dh * H))
@@ -1123,27 +1138,27 @@ class _ForkGatherRows(torch.autograd.Function):
     (a fill and a three-operand pass over (rows, W) for a gather that touches a fraction of the rows)."""
 
     @staticmethod
-    def forward(ctx, src, idx, filt, nfilt):
+    def forward(ctx, src, idx, filt, nfilt, fresh_grad):
         assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
         out = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
         call("mmae_gather_rows", dt(src), idx.numel(), src.shape[1], ptr(src), src.stride(0), ptr(idx), ptr(out),
              out.stride(0), stream())
         ctx.save_for_backward(idx, filt)
-        ctx.cfg = (src.shape, nfilt)
+        ctx.cfg = (src.shape, nfilt, bool(fresh_grad))
         ctx.set_materialize_grads(False)
         return src.view_as(src), out
 
     @staticmethod
     def backward(ctx, g_src, g):
         idx, filt = ctx.saved_tensors
-        shape, nfilt = ctx.cfg
+        shape, nfilt, fresh_grad = ctx.cfg
         if g is None:
-            return g_src, None, None, None
+            return g_src, None, None, None, None
         g = _c(g)
         if g_src is None:
             gs, acc = torch.zeros(shape, dtype=g.dtype, device=g.device), 0
-        elif g_src.is_contiguous() and g_src._base is None and g_src.dtype == g.dtype:
-            gs, acc = g_src, 1              # produced for this node alone (its only consumer is the pass-through output)
+        elif fresh_grad and g_src.is_contiguous() and g_src._base is None and g_src.dtype == g.dtype:
+            gs, acc = g_src, 1              # the caller vouched: produced by the pass-through output's one consumer for this node alone
         else:
             gs, acc = g_src.to(g.dtype).contiguous().clone(), 1
         if filt is None:
@@ -1155,12 +1170,16 @@ class _ForkGatherRows(torch.autograd.Function):
             for f in range(nfilt):
                 call("mmae_scatter_rows", dt(g), idx.numel(), shape[1], ptr(g), g.stride(0), ptr(idx), ptr(gs), gs.stride(0),
                      1 if (acc or f > 0) else 0, ptr(filt), f, stream())
-        return gs, None, None, None
+        return gs, None, None, None, None
 
 
-def fork_gather_rows(src, idx, filt=None, nfilt=0):
-    """-> (src passed through, src[idx]); use the first result in place of `src` for its other consumer."""
-    return _ForkGatherRows.apply(src, idx, filt, nfilt)
+def fork_gather_rows(src, idx, filt=None, nfilt=0, fresh_grad=False):
+    """-> (src passed through, src[idx]); use the first result in place of `src` for its other consumer.
+    fresh_grad: the caller's promise that the pass-through result has exactly ONE consumer and that this consumer's backward
+    returns a tensor it allocated itself and keeps no other reference to (ops.kv_context does) -- only then does the backward
+    add the gathered rows' gradient into that tensor in place; otherwise it works on a copy (an identity-like consumer would
+    hand back a tensor that something else still reads)."""
+    return _ForkGatherRows.apply(src, idx, filt, nfilt, fresh_grad)
 
 
 def gather_rows(src, idx, unique=True, filt=None, nfilt=0):
