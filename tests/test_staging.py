@@ -32,6 +32,21 @@ def test_oracle_area_resize_is_block_mean_and_uint8_rounds():
     assert np.array_equal(S.resize_area(img, 1)[0], img[0])
 
 
+def test_oracle_area_resize_matches_pillow_box_reduce():
+    """A second, independent implementation of box (area) resampling for integer factors: Pillow's Image.reduce on float
+    rasters.  It anchors the float block mean only -- cv2's uint8 rounding stays held to the hand-computed case above (cv2 is
+    absent here: that part of row f3 is still 'parity unpinned')."""
+    Image = pytest.importorskip("PIL.Image")
+    g = np.random.default_rng(5)
+    for f in (2, 3, 4):
+        img = g.normal(0.0, 3.0, size=(2, 12 * f, 8 * f)).astype(np.float32)
+        got = S.resize_area(img, f)
+        for c in range(2):
+            want = np.asarray(Image.fromarray(img[c], mode="F").reduce(f), dtype=np.float32)
+            assert want.shape == got[c].shape
+            assert np.abs(got[c] - want).max() <= 1e-5 * np.abs(img).max(), f
+
+
 def _raw(B, f, seed):
     g = np.random.default_rng(seed)
     n = 256 * f
