@@ -38,6 +38,7 @@ FUSED_FINAL_CAST = True     # bf16 copy of the final norm's output from the same
 FUSED_DECODER_CTX = True    # one GEMM for every decoder's proj_context
 DUAL_LAYERNORM = True       # one pass for the modality rows' two LayerNorm pairs
 DECODER_STREAMS = False     # the per-modality decoders on separate HIP streams (measured: no gain)
+ASYNC_DRAW_COPY = True          # the Dirichlet draw reaches the device through pinned memory, asynchronously (generate_random_masks)
 
 class PredTokens:
     """Decoder output kept token-major, (B*P, C*p*p) in (c ph pw) order, so that the masked loss can be fused with the
@@ -189,9 +190,15 @@ class MultiMAE(nn.Module):
         R = B if self.per_sample_masks else 1
         alphas = [alphas] * M if isinstance(alphas, float) else alphas
         if sample_tasks_uniformly:
-            dist = Dirichlet(self.sample_alphas(R, M, alphas=alphas)).sample().to(device)
+            dist = Dirichlet(self.sample_alphas(R, M, alphas=alphas)).sample()
         else:
-            dist = Dirichlet(torch.Tensor(alphas)).sample((R,)).to(device)
+            dist = Dirichlet(torch.Tensor(alphas)).sample((R,))
+        if device.type == 'cuda' and ASYNC_DRAW_COPY:
+            # through pinned memory, asynchronously: a pageable host->device copy makes the host wait until the stream has drained,
+            # i.e. one host/GPU synchronisation at the top of every step (the GPU then idles while the step's first launches arrive)
+            dist = dist.pin_memory().to(device, non_blocking=True)
+        else:
+            dist = dist.to(device)
         noise = torch.stack([torch.rand(R, P, device=device) for _ in range(M)], dim=1)       # (R, M, P)
         noise_all = torch.rand(R, M * P, device=device)
         mask_all, ids_keep, ids_restore = ops.masks_from_draws(dist, noise, noise_all, num_encoded_tokens)

@@ -10,6 +10,7 @@ The product package reads NO tuning variable itself (only MMAE_HIP_LIB, the libr
     MMAE_DECODER_STREAMS multimae_crossattn.DECODER_STREAMS
     MMAE_SPLITK_CAP / MMAE_SPLITK_MAX / MMAE_WGRAD_PRIO / MMAE_FF_CHUNKS      the ops.py constants of the same names
     MMAE_OWN_GEMM        ops.OWN_GEMM               bit 0: own 8-phase GEMM for forward / input-gradient projections, bit 1: for weight gradients
+    MMAE_ASYNC_DRAW      multimae_crossattn.ASYNC_DRAW_COPY   0: the mask draw's host->device copy from pageable memory (one host/GPU sync per step)
     MMAE_DEFER_SPLITK    ops.DEFER_SPLITK           0: one split-K sum launch per weight gradient instead of one per layer
 """
 import os
@@ -37,6 +38,7 @@ def apply(verbose=True):
     put(mc, "FUSED_DECODER_CTX", "MMAE_FUSED_CTX", flag)
     put(mc, "DUAL_LAYERNORM", "MMAE_DUAL_LN", flag)
     put(mc, "DECODER_STREAMS", "MMAE_DECODER_STREAMS", flag)
+    put(mc, "ASYNC_DRAW_COPY", "MMAE_ASYNC_DRAW", flag)
     if verbose and changed:
         import sys
         print("[tuning_env] " + ", ".join("%s=%s" % kv for kv in sorted(changed.items())), file=sys.stderr)
