@@ -524,6 +524,7 @@ def main():
 
     prof = ops.KernelTimer("mmae_mha_fwd")
     prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
+    prof_ln.every = 3                         # 59 launches per step of the timed instance: every 3rd (rows alternate, 59 is odd: all shapes)
     prof_gemm = ops.KernelTimer("mmae_gemm_nt")
     prof_gemm.every = 7                       # 182 launches per step: every 7th is bracketed (26 per step, all shapes in rotation)
     for _ in range(args.warmup):
@@ -609,7 +610,8 @@ def main():
                          "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (replay_ok and hbm_ok) else None,
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
-                         "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n},
+                         "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n,
+                         "sampling": "every 3rd launch of this kernel instance"},
             # the flagship MFMA kernel of the path (north_star: fusion-attention block), mask-aware algorithmic FLOPs
             "roofline_attention": {"kernel": "+".join(sorted(prof.kernels)) or None,   # as routed by the library (mmae_mha_fwd_route)
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",

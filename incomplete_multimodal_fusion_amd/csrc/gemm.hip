@@ -40,17 +40,19 @@ namespace {
 __device__ __forceinline__ unsigned gm_pack2(float lo, float hi) {          // one v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
-// exact-erf GELU as x * Phi(x), Phi from one exp2 + one rcp (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7): the formula of rowops.hip's
-// geglu_fwd_kernel, so the fused and the separate path round identically
+// exact-erf GELU as x * Phi(x), Phi from one exp2 + one rcp (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7): the approximation of rowops.hip's
+// geglu_fwd_kernel (the two paths agree to fp32 rounding, i.e. to the last bf16 bit in all but boundary cases).
+// The epilogue is VALU-issue bound, so the form with the fewest instructions: the 0.5 of erfc / 2 folded into the coefficients, and
+// x Phi(x) = max(x, 0) - |x| * (erfc(|x| / sqrt 2) / 2) for either sign (one max and one fma instead of compare, select, subtract, multiply).
 __device__ __forceinline__ float gm_gelu(float x) {
     const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float half_erfc = 0.5f * poly * t * e;
-    return x * (x >= 0.f ? 1.f - half_erfc : half_erfc);
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    const float half_erfc = poly * (t * e);
+    return fmaf(-fabsf(x), half_erfc, fmaxf(x, 0.f));
 }
 
 struct GemmArgs {

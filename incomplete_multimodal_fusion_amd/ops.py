@@ -30,6 +30,12 @@ class KernelTimer:
     def __init__(self, name: str):
         self.name, self.pairs, self.flops, self.kernels = name, [], None, set()      # kernels: device kernel names the launches ran
 
+    def sample(self) -> bool:
+        """True for every `every`-th call (default: each one): a bracket costs the stream ~5 us of idle time per event, so a
+        timer on an entry point with many launches per step brackets a rotating subset."""
+        self.seen = getattr(self, "seen", 0) + 1
+        return self.seen % getattr(self, "every", 1) == 0
+
     def bracket(self):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.pairs.append((a, b))
@@ -205,10 +211,8 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None
     y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if out is None else out
     assert y.shape == (M, N) and y.stride(1) == 1 and y.dtype == torch.bfloat16
     tm = _TIMERS.get("mmae_gemm_nt")            # bench.py's roofline_gemm: every `every`-th launch is bracketed (a bracket costs ~5 us)
-    if tm is not None:
-        tm.seen = getattr(tm, "seen", 0) + 1
-        if tm.seen % getattr(tm, "every", 1):
-            tm = None
+    if tm is not None and not tm.sample():
+        tm = None
     if tm is not None:
         tm.add_flops(2.0 * M * N * K)
         ev0, ev1 = tm.bracket()
@@ -891,6 +895,8 @@ class _PartsAddLN(torch.autograd.Function):
                                        up is not None and gx is not None and off >= 0):
                 tm = None       # time ONE template instance only: add_ln_bwd_fast_kernel<bf16, bf16, 3, double, up, gx, gdelta>
                                 # (the encoder's residual passes: 59 of the 72 launches of this entry point per step at ViT-B)
+            if tm is not None and not tm.sample():
+                tm = None
             if tm is not None:
                 # algorithmic bytes: x_new (4) + gy + [gx_up (4)] read, [gx (4)] + [gdelta] written, per element
                 per = 4 + gy.element_size() + (4 if up is not None else 0) + (4 if gx is not None else 0) + \
