@@ -41,6 +41,47 @@ def test_gemm_nt_matches_fp32_reference(M, N, K):
     assert torch.equal(ops.gemm_nt(a, w), y)
 
 
+# every forward / input-gradient projection of the bench step (ViT-B, B = 256: 163 840 encoder rows, 65 536 fusion rows, 164 096 key rows)
+_R, _RF, _RK = 256 * 640, 256 * 256, 256 * 640 + 256
+BENCH_SHAPES = [(_R, 1536, 768), (_R, 768, 512), (_R, 768, 2048), (_RK, 1024, 768), (_RF, 512, 768), (_RF, 768, 512), (_RF, 768, 2048),
+                (_R, 768, 1536), (_R, 512, 768), (_R, 2048, 768), (_R, 768, 4096), (_RK, 768, 1024), (_RF, 2048, 768), (_RF, 768, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", BENCH_SHAPES)
+def test_gemm_nt_bench_shapes(M, N, K):
+    """The persistent kernel at the sizes the benchmark runs (640+ M-panels: every workgroup walks several tiles, the XCD chunking and the
+    rolled epilogue across tile seams are all exercised): row blocks from the start, the middle, every XCD's share and the end of the
+    output against the fp32 product of the same bf16 operands."""
+    from incomplete_multimodal_fusion_amd import ops
+    a, w = _operands(M, N, K, seed=N + K)
+    y = ops.gemm_nt(a, w)
+    wt = w.float().t()
+    starts = sorted({0, 256, M // 8 + 37, M // 3, M // 2 - 129, 5 * (M // 8) + 1000, M - 3 * 256 - 5, M - 300})
+    for r0 in starts:
+        close(y[r0:r0 + 300], a[r0:r0 + 300].float() @ wt, 1e-2, "rows %d.. of %s" % (r0, (M, N, K)))
+    assert torch.isfinite(y.float()).all()
+    assert torch.equal(ops.gemm_nt(a, w), y), "bitwise reproducible"
+
+
+@pytest.mark.parametrize("M", [_R, _RF])
+def test_gemm_geglu_bench_shapes(M):
+    """FeedForward[1] + GEGLU at the bench rows (F = 2048, K = 768): h and the product on sampled row blocks."""
+    from incomplete_multimodal_fusion_amd import ops
+    from oracle import mmae_oracle as O
+    F, K = 2048, 768
+    a, w1 = _operands(M, 2 * F, K, seed=M)
+    h = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+    g = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_geglu(a, w1, h, g)
+    wt = w1.float().t()
+    for r0 in sorted({0, M // 8 + 37, M // 2 - 129, 5 * (M // 8) + 1000, M - 300}):
+        ref_h = a[r0:r0 + 300].float() @ wt
+        close(h[r0:r0 + 300], ref_h, 1e-2, "h rows %d" % r0)
+        h64 = ref_h.double()
+        close(g[r0:r0 + 300], O.gelu_erf(h64[:, F:]) * h64[:, :F], 1e-2, "g rows %d" % r0)
+    assert torch.isfinite(h.float()).all() and torch.isfinite(g.float()).all()
+
+
 def test_gemm_nt_leading_dimensions_and_output_view():
     """Operands that are column blocks of wider matrices (lda / ldw > K) and an output written into a column block (ldc > N): the untouched
     columns of the output matrix must stay untouched."""
