@@ -41,8 +41,9 @@ def timed(fn, it=10, rounds=3):
 for name, rows, N, Kin in SHAPES:
     if only and only not in name:
         continue
-    g = (torch.rand(rows, N, device="cuda") * 2 - 1).to(torch.bfloat16)
-    x = (torch.rand(rows, Kin, device="cuda") * 2 - 1).to(torch.bfloat16)
+    pad = int(os.environ.get("WGRAD_PAD", "0"))          # elements added to both leading dimensions (power-of-two row strides or not)
+    g = (torch.rand(rows, N + pad, device="cuda") * 2 - 1).to(torch.bfloat16)[:, :N]
+    x = (torch.rand(rows, Kin + pad, device="cuda") * 2 - 1).to(torch.bfloat16)[:, :Kin]
     out = torch.empty(N, Kin, device="cuda")
 
     def lib():
