@@ -147,98 +147,190 @@ extern "C" int mmae_dino_loss_bwd(int B, int D, const float* student, const floa
 }
 
 // ------------------------------------------------------------------------------------------ hard-negative NT-Xent
-// One block.  n = 2B rows; out = cat(normalize(o1), normalize(o2)).  LDS holds the normalised rows' Gram matrix
-// E[i][j] = exp(<out_i, out_j> / T).  For row i:  neg = {E[i][j] : j mod B != i mod B},  pos_i = E[i][(i+B) mod n],
+// n = 2B rows; out = cat(normalize(o1), normalize(o2)); E[i][j] = exp(<out_i, out_j> / T).  For row i:
+//   neg = {E[i][j] : j mod B != i mod B},  pos_i = E[i][(i+B) mod n],
 //   imp = neg^beta,  rw = sum(imp*neg) / mean(imp),  Ng = max((-tau*N*pos + rw) / (1 - tau), N*e^(-1/T)),  N = n - 2,
 //   loss = mean_i -log(pos / (pos + Ng)).
-// Backward: dL/dE analytically, then dL/dout = (dE o E)/T-weighted sums of rows (E is symmetric: both roles of a row
-// are accumulated), then through the row normalisation.
+// Backward: dL/dE analytically (G = dL/dS, S = <u_i,u_j>/T), then dL/du_i = sum_j (G[i][j] + G[j][i]) u_j (E is symmetric: both
+// roles of a row), then through the row normalisation.
+// A chain of small kernels over the whole chip, fixed summation orders (no atomics): rows -> Gram tiles -> per-row statistics
+// (+ G) -> loss mean | (G + G^T) U tiles -> normalisation backward.  The first version ran the whole head in ONE workgroup:
+// 3.2 ms per call at B = 64, D = 1024 (n^2 = 16 k dot products of 1024 on one CU) -- 27 % of BASELINE config 5's step.
 struct HnDesc {
     const float* o1; const float* o2; float* loss; const float* gloss; float* g1; float* g2;
-    float* ws;     // workspace: n*D (normalised rows) + n*n (E) + n*n (dL/dS) + n (norms) floats
+    float* ws;     // workspace: n*D (normalised rows) + n*n (E) + n*n (dL/dS) + n (norms) + n (row losses) floats
     int B, D; float tau_plus, beta, temperature;
 };
+__device__ __forceinline__ float* hn_U(const HnDesc& d) { return d.ws; }
+__device__ __forceinline__ float* hn_E(const HnDesc& d) { return d.ws + 2L * d.B * d.D; }
+__device__ __forceinline__ float* hn_G(const HnDesc& d) { return hn_E(d) + 4L * d.B * d.B; }
+__device__ __forceinline__ float* hn_nrm(const HnDesc& d) { return hn_G(d) + 4L * d.B * d.B; }
+__device__ __forceinline__ float* hn_rowl(const HnDesc& d) { return hn_nrm(d) + 2L * d.B; }
 
-__global__ __launch_bounds__(1024) void hardneg_kernel(HnDesc d, int backward) {
-    const int n = 2 * d.B, D = d.D, tid = threadIdx.x, nt = blockDim.x;
-    float* U = d.ws;                 // (n, D) normalised rows
-    float* E = U + (long)n * D;      // (n, n)
-    float* G = E + (long)n * n;      // (n, n) dL/dS where S = <u_i,u_j>/T
-    float* nrm = G + (long)n * n;    // (n)
-    float* rowl = nrm + n;           // (n) per-row loss
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    for (int i = wave; i < n; i += nw) {
-        const float* src = i < d.B ? d.o1 + (long)i * D : d.o2 + (long)(i - d.B) * D;
-        float a = 0.f;
-        for (int c = lane; c < D; c += 64) a += src[c] * src[c];
-        const float nm = fmaxf(sqrtf(wave_sum(a)), 1e-12f);
-        for (int c = lane; c < D; c += 64) U[(long)i * D + c] = src[c] / nm;
-        if (lane == 0) nrm[i] = nm;
+// one wave per row: u = s / max(|s|, 1e-12)
+__global__ __launch_bounds__(256) void hn_normalize_kernel(HnDesc d) {
+    const int n = 2 * d.B, D = d.D, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* src = i < d.B ? d.o1 + (long)i * D : d.o2 + (long)(i - d.B) * D;
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += src[c] * src[c];
+    const float nm = fmaxf(sqrtf(wave_sum(a)), 1e-12f);
+    float* U = hn_U(d);
+    for (int c = lane; c < D; c += 64) U[(long)i * D + c] = src[c] / nm;
+    if (lane == 0) hn_nrm(d)[i] = nm;
+}
+
+// E tile of 32 x 32 per workgroup: 256 threads, thread (ty, tx) owns E[i0 + ty + 8 r][j0 + tx], r = 0..3; D walked in chunks of 32
+// through LDS (rows padded to 33 floats: conflict-free for both operands)
+__global__ __launch_bounds__(256) void hn_gram_kernel(HnDesc d) {
+    __shared__ float A[32][33], Bt[32][33];
+    const int n = 2 * d.B, D = d.D, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const float* U = hn_U(d);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < D; c0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ty + 8 * r, c = c0 + tx;
+            A[row][tx] = (i0 + row < n && c < D) ? U[(long)(i0 + row) * D + c] : 0.f;
+            Bt[row][tx] = (j0 + row < n && c < D) ? U[(long)(j0 + row) * D + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float b = Bt[tx][k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(A[ty + 8 * r][k], b, acc[r]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int ij = wave; ij < n * n; ij += nw) {
-        const int i = ij / n, j = ij % n;
-        float a = 0.f;
-        for (int c = lane; c < D; c += 64) a += U[(long)i * D + c] * U[(long)j * D + c];
-        a = wave_sum(a);
-        if (lane == 0) E[ij] = expf(a / d.temperature);
+    float* E = hn_E(d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < n && j < n) E[(long)i * n + j] = expf(acc[r] / d.temperature);
     }
-    __syncthreads();
+}
+
+// one wave per row: the row's statistics, its loss and (backward) its row of G
+__global__ __launch_bounds__(256) void hn_rows_kernel(HnDesc d, int backward) {
+    const int n = 2 * d.B, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* E = hn_E(d) + (long)i * n;
     const float Nn = (float)(n - 2);
     const float clampv = Nn * expf(-1.f / d.temperature);
-    for (int i = wave; i < n; i += nw) {
-        const int ib = i % d.B;
-        float simp = 0.f, sin_ = 0.f;
-        for (int j = lane; j < n; j += 64) {
-            if (j % d.B != ib) { const float e = E[i * n + j]; const float imp = powf(e, d.beta); simp += imp; sin_ += imp * e; }
+    const int ib = i % d.B;
+    float simp = 0.f, sin_ = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        if (j % d.B != ib) { const float e = E[j]; const float imp = powf(e, d.beta); simp += imp; sin_ += imp * e; }
+    }
+    simp = wave_sum(simp); sin_ = wave_sum(sin_);
+    const float pos = E[(i + d.B) % n];
+    const float meanimp = simp / Nn;
+    const float rw = sin_ / meanimp;
+    const float raw = (-d.tau_plus * Nn * pos + rw) / (1.f - d.tau_plus);
+    const bool clamped = raw < clampv;
+    const float Ng = clamped ? clampv : raw;
+    if (lane == 0) hn_rowl(d)[i] = -logf(pos / (pos + Ng));
+    if (!backward) return;
+    // loss_i = log(pos + Ng) - log(pos)
+    const float gi = d.gloss[0] / (float)n;
+    const float dNg = clamped ? 0.f : gi / (pos + Ng);
+    const float dpos = gi * (1.f / (pos + Ng) - 1.f / pos) + dNg * (-d.tau_plus * Nn) / (1.f - d.tau_plus);
+    const float drw = dNg / (1.f - d.tau_plus);
+    float* G = hn_G(d) + (long)i * n;
+    // rw = Nn * sin_ / simp ; imp = e^beta
+    for (int j = lane; j < n; j += 64) {
+        float ge = 0.f;
+        const float e = E[j];
+        if (j % d.B != ib) {
+            const float imp = powf(e, d.beta);
+            const float dimp_de = d.beta * imp / e;
+            // d(sin_)/de = dimp_de*e + imp ; d(simp)/de = dimp_de
+            ge = drw * Nn * ((dimp_de * e + imp) / simp - sin_ * dimp_de / (simp * simp));
         }
-        simp = wave_sum(simp); sin_ = wave_sum(sin_);
-        const float pos = E[i * n + (i + d.B) % n];
-        const float meanimp = simp / Nn;
-        const float rw = sin_ / meanimp;
-        const float raw = (-d.tau_plus * Nn * pos + rw) / (1.f - d.tau_plus);
-        const bool clamped = raw < clampv;
-        const float Ng = clamped ? clampv : raw;
-        if (lane == 0) rowl[i] = -logf(pos / (pos + Ng));
-        if (backward) {
-            // loss_i = log(pos + Ng) - log(pos)
-            const float gi = d.gloss[0] / (float)n;
-            const float dNg = clamped ? 0.f : gi / (pos + Ng);
-            const float dpos = gi * (1.f / (pos + Ng) - 1.f / pos) + dNg * (-d.tau_plus * Nn) / (1.f - d.tau_plus);
-            const float drw = dNg / (1.f - d.tau_plus);
-            // rw = Nn * sin_ / simp ; imp = e^beta
-            for (int j = lane; j < n; j += 64) {
-                float ge = 0.f;
-                if (j % d.B != ib) {
-                    const float e = E[i * n + j];
-                    const float imp = powf(e, d.beta);
-                    const float dimp_de = d.beta * imp / e;
-                    // d(sin_)/de = dimp_de*e + imp ; d(simp)/de = dimp_de
-                    ge = drw * Nn * ((dimp_de * e + imp) / simp - sin_ * dimp_de / (simp * simp));
-                }
-                if (j == (i + d.B) % n) ge += dpos;
-                G[i * n + j] = ge * E[i * n + j] / d.temperature;      // dL/d<u_i,u_j> contribution of row i
+        if (j == (i + d.B) % n) ge += dpos;
+        G[j] = ge * e / d.temperature;                 // dL/d<u_i,u_j> contribution of row i
+    }
+}
+
+__global__ __launch_bounds__(64) void hn_loss_kernel(HnDesc d) {
+    const int n = 2 * d.B;
+    if (threadIdx.x == 0) { float a = 0.f; for (int i = 0; i < n; ++i) a += hn_rowl(d)[i]; d.loss[0] = a / (float)n; }   // fixed order
+}
+
+// du tile: 16 rows x 256 columns per workgroup (thread = one column): du_i[c] = sum_j (G[i][j] + G[j][i]) u_j[c], j in ascending
+// order; the 16 x n block of G + G^T is staged in LDS in chunks of 128 columns of j
+__global__ __launch_bounds__(256) void hn_du_kernel(HnDesc d) {
+    __shared__ float H[16][129];
+    const int n = 2 * d.B, D = d.D, tid = threadIdx.x;
+    const int i0 = blockIdx.y * 16, c = blockIdx.x * 256 + tid;
+    const float* G = hn_G(d);
+    const float* U = hn_U(d);
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int jb = 0; jb < n; jb += 128) {
+        for (int e = tid; e < 16 * 128; e += 256) {
+            const int r = e >> 7, jj = e & 127, i = i0 + r, j = jb + jj;
+            H[r][jj] = (i < n && j < n) ? G[(long)i * n + j] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * 128; e += 256) {                       // + G^T: 16 consecutive floats of row j
+            const int jj = e >> 4, r = e & 15, i = i0 + r, j = jb + jj;
+            if (i < n && j < n) H[r][jj] += G[(long)j * n + i];
+        }
+        __syncthreads();
+        const int jn = min(128, n - jb);
+        if (c < D) {
+            for (int jj = 0; jj < jn; ++jj) {
+                const float u = U[(long)(jb + jj) * D + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaf(H[r][jj], u, acc[r]);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    if (!backward) {
-        if (tid == 0) { float a = 0.f; for (int i = 0; i < n; ++i) a += rowl[i]; d.loss[0] = a / (float)n; }
-        return;
-    }
-    // du_i = sum_j (G[i][j] + G[j][i]) u_j ; then through normalisation: ds = (du - u <u,du>) / |s|
-    for (int i = wave; i < n; i += nw) {
-        float dot = 0.f;
-        float* dst = i < d.B ? d.g1 + (long)i * D : d.g2 + (long)(i - d.B) * D;
-        for (int c = lane; c < D; c += 64) {
-            float a = 0.f;
-            for (int j = 0; j < n; ++j) a += (G[i * n + j] + G[j * n + i]) * U[(long)j * D + c];
-            dst[c] = a;                       // temporarily du
-            dot += a * U[(long)i * D + c];
+    if (c < D) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + r;
+            if (i < n) (i < d.B ? d.g1 + (long)i * D : d.g2 + (long)(i - d.B) * D)[c] = acc[r];      // du, finished below
         }
-        dot = wave_sum(dot);
-        for (int c = lane; c < D; c += 64) dst[c] = (dst[c] - U[(long)i * D + c] * dot) / nrm[i];
     }
+}
+
+// one wave per row, through the normalisation: ds = (du - u <u, du>) / |s|
+__global__ __launch_bounds__(256) void hn_finish_kernel(HnDesc d) {
+    const int n = 2 * d.B, D = d.D, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float* dst = i < d.B ? d.g1 + (long)i * D : d.g2 + (long)(i - d.B) * D;
+    const float* u = hn_U(d) + (long)i * D;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot += dst[c] * u[c];
+    dot = wave_sum(dot);
+    const float nm = hn_nrm(d)[i];
+    for (int c = lane; c < D; c += 64) dst[c] = (dst[c] - u[c] * dot) / nm;
+}
+
+static int hardneg_launch(const HnDesc& d, int backward, hipStream_t st) {
+    const int n = 2 * d.B;
+    MMAE_LAUNCH(hn_normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    MMAE_LAUNCH(hn_gram_kernel, dim3(cdiv(n, 32), cdiv(n, 32)), dim3(256), 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    MMAE_LAUNCH(hn_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, d, backward);
+    MMAE_CHECK_LAUNCH();
+    if (!backward) {
+        MMAE_LAUNCH(hn_loss_kernel, dim3(1), dim3(64), 0, st, d);
+        MMAE_CHECK_LAUNCH();
+        return MMAE_OK;
+    }
+    MMAE_LAUNCH(hn_du_kernel, dim3(cdiv(d.D, 256), cdiv(n, 16)), dim3(256), 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    MMAE_LAUNCH(hn_finish_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
 }
 
 extern "C" long mmae_hardneg_ws_floats(int B, int D) { const long n = 2L * B; return n * D + 2 * n * n + 2 * n; }
@@ -247,15 +339,11 @@ extern "C" int mmae_hardneg_loss_fwd(int B, int D, const float* out_1, const flo
                                      float temperature, float* ws, float* loss, void* stream) {
     if (B <= 1 || D <= 0 || !out_1 || !out_2 || !ws || !loss) return MMAE_ERR_ARG;
     HnDesc d{out_1, out_2, loss, nullptr, nullptr, nullptr, ws, B, D, tau_plus, beta, temperature};
-    MMAE_LAUNCH(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 0);
-    MMAE_CHECK_LAUNCH();
-    return MMAE_OK;
+    return hardneg_launch(d, 0, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int mmae_hardneg_loss_bwd(int B, int D, const float* out_1, const float* out_2, float tau_plus, float beta,
                                      float temperature, float* ws, const float* gloss, float* g1, float* g2, void* stream) {
     if (B <= 1 || D <= 0 || !out_1 || !out_2 || !ws || !gloss || !g1 || !g2) return MMAE_ERR_ARG;
     HnDesc d{out_1, out_2, nullptr, gloss, g1, g2, ws, B, D, tau_plus, beta, temperature};
-    MMAE_LAUNCH(hardneg_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d, 1);
-    MMAE_CHECK_LAUNCH();
-    return MMAE_OK;
+    return hardneg_launch(d, 1, reinterpret_cast<hipStream_t>(stream));
 }
