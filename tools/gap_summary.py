@@ -42,3 +42,28 @@ print("idle time by gap length: " + ", ".join("%s us: %.2f ms" % (("%d-%d" % (k,
 print("\n| ended -> started | gaps | total idle ms | mean us |\n|---|---|---|---|")
 for k, (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:30]:
     print("| `%s` -> `%s` | %d | %.3f | %.1f |" % (k[0], k[1], c, t / 1e6, t / c / 1e3))
+
+# exclusive time: the part of a kernel's [start, end) during which NO other kernel runs -- what removing that launch could give back
+ev = []
+for idx, (s_, e_, n_) in enumerate(rows):
+    ev.append((s_, 1, idx)); ev.append((e_, 0, idx))
+ev.sort()
+active, excl, last_t = set(), collections.Counter(), ev[0][0]
+for t, kind, idx in ev:
+    if len(active) == 1 and t > last_t:
+        excl[next(iter(active))] += t - last_t
+    last_t = t
+    if kind:
+        active.add(idx)
+    else:
+        active.discard(idx)
+by = collections.defaultdict(lambda: [0, 0, 0])
+for idx, (s_, e_, n_) in enumerate(rows):
+    b = by[short(n_)]
+    b[0] += 1; b[1] += e_ - s_; b[2] += excl[idx]
+small = [(k, v) for k, v in by.items() if v[1] / v[0] < 15000]
+print("\nkernels under 15 us on average: %d launches, %.2f ms of duration, %.2f ms of it exclusive (nothing else running)" %
+      (sum(v[0] for _, v in small), sum(v[1] for _, v in small) / 1e6, sum(v[2] for _, v in small) / 1e6))
+print("\n| kernel (< 15 us) | launches | duration ms | exclusive ms |\n|---|---|---|---|")
+for k, v in sorted(small, key=lambda kv: -kv[1][2])[:16]:
+    print("| `%s` | %d | %.3f | %.3f |" % (k, v[0], v[1] / 1e6, v[2] / 1e6))
