@@ -25,17 +25,17 @@ x = {"s1": torch.randn(B, 1, 256, 256, device=dev), "s2": torch.randn(B, 3, 256,
 for _ in range(3):
     step(x)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True, experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step(x)
     torch.cuda.synchronize()
-want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::zeros", "aten::mul", "aten::sum", "aten::cat", "aten::to", "aten::_to_copy")
+want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::contiguous", "aten::clone", "aten::index_select", "aten::sum", "aten::cat")
 by = collections.defaultdict(collections.Counter)
 events = prof.events()
 for e in events:
     if e.name not in want:
         continue
     frames = [f for f in (e.stack or []) if "incomplete_multimodal_fusion_amd" in f or "bench" in f]
-    where = frames[0].split("incomplete_multimodal_fusion_amd/")[-1] if frames else "(autograd engine / no repo frame)"
+    where = " < ".join(f.split("incomplete_multimodal_fusion_amd/")[-1] for f in frames[:3]) if frames else "(autograd engine / no repo frame)"
     p = e.cpu_parent
     node = ""
     while p is not None:
@@ -44,11 +44,11 @@ for e in events:
             break
         p = p.cpu_parent
     shapes = str(e.input_shapes)[:60]
-    by[e.name][(where[:90], node[:50], shapes)] += 1
+    by[e.name][(where[:150], node[:40], shapes)] += 1
 for name in want:
     tot = sum(by[name].values())
     if not tot:
         continue
     print("\n%s: %d" % (name, tot))
-    for (where, node, shapes), c in by[name].most_common(14):
-        print("   %4d  %-90s %-50s %s" % (c, where, node, shapes))
+    for (where, node, shapes), c in by[name].most_common(30):
+        print("   %4d  %-150s %-40s %s" % (c, where, node, shapes))
