@@ -73,8 +73,14 @@ def lib():
 _ERR = {-1: "invalid argument (MMAE_ERR_ARG)", -2: "HIP launch failed (MMAE_ERR_LAUNCH)"}
 
 
+_FN = {}          # entry point name -> ctypes function object (a getattr on the CDLL per launch costs more than the launch)
+
+
 def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
         detail = ""
         if rc == -2:
@@ -94,9 +100,23 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_RAW = None
+
+
+def raw_stream() -> int:
+    """hipStream_t of torch's current stream on the current device, as an integer (0 = the default stream).  Through the two C
+    accessors: torch.cuda.current_stream() builds a Stream object behind three Python layers (~10 us -- there are ~500 launches
+    per step, and the small configurations are host-bound)."""
+    global _RAW
+    if _RAW is None:
+        import torch
+        torch.cuda.current_stream()                       # lazy CUDA init, once
+        _RAW = (torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice)
+    return _RAW[0](_RAW[1]())
+
+
 def stream():
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def dt(t_or_dtype):

@@ -423,7 +423,7 @@ def _wgrad(g2, x2, gview, publish=None):
         part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
         if part.dtype == torch.bfloat16 and (n_out * n_in) % 8 == 0:
             out = gview if gview is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device)
-            if publish is not None and gview is not None and DEFER_SPLITK and torch.cuda.current_stream() == torch.cuda.default_stream():
+            if publish is not None and gview is not None and DEFER_SPLITK and _lib.raw_stream() == 0:      # the default stream
                 _SPLITK_Q.append((part, S, n_out * n_in, out, publish))
                 if not _SPLITK_CB[0]:
                     _SPLITK_CB[0] = True
