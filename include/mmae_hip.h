@@ -22,9 +22,10 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 4   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
+#define MMAE_ABI_VERSION 5   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
                                 mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
-                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn, mmae_splitk_sum_multi */
+                                mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn, mmae_splitk_sum_multi.  5: the optimizer control block grew
+                                from 4 to 8 floats (mmae_adamw_control / _step_ctl read [4], [5]); + mmae_adamw_tick, mmae_mha_fwd_route */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -193,15 +194,21 @@ int mmae_adamw_step(long n, float* p, const float* g, float* m, float* v, void* 
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* Device-side gradient clipping / step skipping (PT/utils/native_scaler.py:20-40: clip_grad -> clip_grad_norm_, skip_grad ->
  * no optimizer step when norm >= skip_grad; torch GradScaler: no step on a non-finite gradient) without the host round trip.
- * mmae_adamw_control reads the norm mmae_grad_norm left on the device and fills ctl4 (4 floats, zero-initialised once by the
- * caller): [0] gradient multiplier = grad_scale * min(1, max_norm / (norm*|grad_scale| + 1e-6)) (max_norm 0: no clipping),
- * [1] 1 when the step is skipped (norm non-finite and check_finite, or skip_norm > 0 and norm >= skip_norm), [2] running count of skipped
- * steps, [3] the unscaled norm.  mmae_adamw_step_ctl is mmae_adamw_step taking the multiplier / skip flag from ctl4 and
- * bias-correcting with step - ctl4[2], i.e. exactly as if optimizer.step() had not been called for skipped steps. */
+ * mmae_adamw_control reads the norm mmae_grad_norm left on the device and fills ctl8 (8 floats since ABI 5 -- ABI 4 took 4 --,
+ * zero-initialised once by the caller): [0] gradient multiplier = grad_scale * min(1, max_norm / (norm*|grad_scale| + 1e-6))
+ * (max_norm 0: no clipping), [1] 1 when the step is skipped (norm non-finite and check_finite, or skip_norm > 0 and norm >=
+ * skip_norm), [2] running count of skipped steps, [3] the unscaled norm.  mmae_adamw_step_ctl is mmae_adamw_step taking the
+ * multiplier / skip flag from ctl8 and bias-correcting with step - ctl8[2], i.e. exactly as if optimizer.step() had not been
+ * called for skipped steps.
+ * Steps captured in a hipGraph replay their launches with the captured by-value arguments, so the two that change per step live
+ * in ctl8 as well: [4] replays so far -- mmae_adamw_tick adds 1, captured at the top of the step; mmae_adamw_step_ctl adds it to
+ * `step` --, [5] / [6] the learning rate / weight decay of this replay, used when [7] != 0 (the host writes them before the
+ * replay).  All stay 0 outside a graph. */
 int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale, int check_finite,
-                       float* ctl4, void* stream);
+                       float* ctl8, void* stream);
+int mmae_adamw_tick(float* ctl8, void* stream);
 int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, int step, const float* ctl4, void* stream);
+                        float beta2, float eps, float weight_decay, int step, const float* ctl8, void* stream);
 int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);
 /* Transposed bf16 copies of many 2-D weights in ONE launch (the data-gradient GEMMs of ops._Linear read W^T; torch did one
  * `w.t().contiguous()` kernel per weight per step).  One 64x64 tile per row of `tiles`, 32 bytes each:

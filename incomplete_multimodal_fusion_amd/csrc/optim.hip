@@ -13,6 +13,9 @@
 // found-inf check): ctl[0] = multiplier applied to every gradient element (grad_scale x clip coefficient), ctl[1] = 1 when
 // this step must not be taken, ctl[2] = number of steps skipped so far (the bias correction uses step - ctl[2], exactly as if
 // optimizer.step() had not been called), ctl[3] = the unscaled gradient norm.
+// Captured steps (a hipGraph replays the launch with the SAME by-value arguments): ctl[4] = replays so far, advanced by
+// adamw_tick_kernel at the top of every replay and added to the captured step count; ctl[7] != 0: ctl[5] / ctl[6] are the learning
+// rate / weight decay of this replay (written by the host before it, overriding the captured ones).  All stay 0 outside a graph.
 __global__ void adamw_control_kernel(const float* __restrict__ norm, float max_norm, float skip_norm, float grad_scale,
                                      int guard, float* __restrict__ ctl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -36,7 +39,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (ctl) {
         if (ctl[1] != 0.f) return;                      // skipped step: weights, moments and shadow stay as they are
         grad_scale = ctl[0];
-        step -= (int)ctl[2];
+        step += (int)ctl[4] - (int)ctl[2];
+        if (ctl[7] != 0.f) { lr = ctl[5]; wd = ctl[6]; }
     }
     const float inv_bc1 = 1.f / (1.f - powf(b1, (float)step));
     const float inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, (float)step));
@@ -198,19 +202,30 @@ extern "C" int mmae_adamw_step(long n, float* p, const float* g, float* m, float
 }
 
 extern "C" int mmae_adamw_control(const float* grad_norm, float max_norm, float skip_norm, float grad_scale,
-                                  int check_finite, float* ctl4, void* stream) {
-    if (!grad_norm || !ctl4 || max_norm < 0.f || skip_norm < 0.f) return MMAE_ERR_ARG;
+                                  int check_finite, float* ctl8, void* stream) {
+    if (!grad_norm || !ctl8 || max_norm < 0.f || skip_norm < 0.f) return MMAE_ERR_ARG;
     MMAE_LAUNCH(adamw_control_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), grad_norm, max_norm,
-                       skip_norm, grad_scale, check_finite, ctl4);
+                       skip_norm, grad_scale, check_finite, ctl8);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+__global__ void adamw_tick_kernel(float* __restrict__ ctl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl[4] += 1.f;
+}
+
+extern "C" int mmae_adamw_tick(float* ctl8, void* stream) {
+    if (!ctl8) return MMAE_ERR_ARG;
+    MMAE_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl8);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
 
 extern "C" int mmae_adamw_step_ctl(long n, float* p, const float* g, float* m, float* v, void* shadow_bf16, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, int step, const float* ctl4,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, const float* ctl8,
                                    void* stream) {
-    if (!ctl4) return MMAE_ERR_ARG;
-    return adamw_launch(n, p, g, m, v, shadow_bf16, lr, beta1, beta2, eps, weight_decay, step, 1.f, ctl4, stream);
+    if (!ctl8) return MMAE_ERR_ARG;
+    return adamw_launch(n, p, g, m, v, shadow_bf16, lr, beta1, beta2, eps, weight_decay, step, 1.f, ctl8, stream);
 }
 
 extern "C" int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream) {

@@ -47,7 +47,10 @@ class FlatAdamW:
         self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
         self._ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self._norm = torch.empty(1, dtype=torch.float32, device=dev)
-        self._ctl = torch.zeros(4, dtype=torch.float32, device=dev)     # mmae_adamw_control: multiplier, skip, #skipped, norm
+        # mmae_adamw_control: multiplier, skip, #skipped, norm | captured steps: [4] replays so far, [5] this replay's learning rate
+        self._ctl = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._capturing = False            # step() is being captured into a hipGraph (begin_capture / end_capture)
+        self._graph_lr = None              # (learning rate, weight decay) last written to _ctl[5:7]
         self._ctl_used = False
         self._pstep: Dict[int, int] = {id(p): 0 for p in self.params}    # per-parameter step counts, as torch keeps them
         self._in_place = set()             # ids of weights whose gradient a producer wrote in place since zero_grad()
@@ -179,7 +182,11 @@ class FlatAdamW:
         g = self.param_groups[0]
         self.flush()
         self.steps += 1
-        ctl = clip_grad is not None or skip_grad is not None or check_finite
+        ctl = clip_grad is not None or skip_grad is not None or check_finite or self._capturing
+        if self._capturing:
+            # the launches below are replayed with THESE by-value arguments: the replay count the device keeps is added to the
+            # captured step counts (hence the - 1 below: the first replay is the step this call would have been)
+            call("mmae_adamw_tick", ptr(self._ctl), stream())
         if not ctl and self._ctl_used:
             # once a controlled step has run, the device holds the count of skipped steps the bias correction needs: an
             # uncontrolled step afterwards goes through the same kernel (no threshold, no guard) instead of using a host count
@@ -199,19 +206,53 @@ class FlatAdamW:
             if ctl:
                 call("mmae_adamw_step_ctl", n, ptr(self.master[sl]), ptr(self.grads[sl]), ptr(self.exp_avg[sl]),
                      ptr(self.exp_avg_sq[sl]), ptr(self.shadow[sl]), lr, self.betas[0], self.betas[1], self.eps,
-                     float(g["weight_decay"]), st, ptr(self._ctl), stream())
+                     float(g["weight_decay"]), st - 1 if self._capturing else st, ptr(self._ctl), stream())
             else:
                 call("mmae_adamw_step", n, ptr(self.master[sl]), ptr(self.grads[sl]), ptr(self.exp_avg[sl]),
                      ptr(self.exp_avg_sq[sl]), ptr(self.shadow[sl]), lr, self.betas[0], self.betas[1], self.eps,
                      float(g["weight_decay"]), st, float(grad_scale), stream())
         if ctl:
             absent = [p for p in self.params if p.grad is None]
+            if self._capturing and absent:
+                raise RuntimeError("a captured step needs every parameter of the engine to receive a gradient (exclude the rest: "
+                                   "FlatAdamW(..., exclude=model.never_used_parameters()))")
             if absent and self.last_step_skipped():
                 # the kernels bias-correct with (host count - skipped steps so far); a parameter that sat this skipped step
                 # out must not lose a step for it.  Host sync, only when the set of used parameters varies (downstream).
                 for p in absent:
                     self._pstep[id(p)] += 1
         self._refresh_transposed()
+
+    # -- hipGraph capture of the step (pretrain.PretrainStep.capture) ---------------------------------------------------
+    def begin_capture(self):
+        """The following step() is being captured: it always takes the device-controlled path, reads its step counts and
+        learning rate through the control block (the captured launches keep their by-value arguments) and needs a gradient for
+        every parameter.  After end_capture() use replay_begin() / replay_end() around each graph replay; eager step() calls must
+        not be mixed in any more (the device's replay count would no longer match the host's step count)."""
+        self._capturing = True
+        self._ctl[4:8].zero_()
+        self._graph_lr = None
+
+    def end_capture(self):
+        """The captured step() only recorded launches: take back the host-side counts it advanced."""
+        self._capturing = False
+        self.steps -= 1
+        for p in self.params:
+            self._pstep[id(p)] -= 1
+
+    def replay_begin(self):
+        """Before a graph replay: hand the current learning rate / weight decay to the device (one tiny copy, only when they changed)."""
+        g = self.param_groups[0]
+        hyper = (float(g["lr"]) * float(g.get("lr_scale", 1.0)), float(g["weight_decay"]))
+        if hyper != self._graph_lr:
+            self._ctl[5:8].copy_(torch.tensor([hyper[0], hyper[1], 1.0], dtype=torch.float32).pin_memory(), non_blocking=True)
+            self._graph_lr = hyper
+
+    def replay_end(self):
+        """After a graph replay: the host's view of the step counts."""
+        self.steps += 1
+        for p in self.params:
+            self._pstep[id(p)] += 1
 
     def skip_flag(self) -> Optional[torch.Tensor]:
         """Device bool scalar: did the device-side control skip the most recent step()?  None when that step was not a controlled

@@ -177,6 +177,13 @@ class MultiMAE(nn.Module):
         pick = torch.randint(0, len(choices), (B,))
         return torch.index_select(choices, 0, pick) * torch.tensor(alphas) + eps
 
+    def draw_mask_distribution(self, R: int, M: int, alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False):
+        """The host-side draw of generate_random_masks (reference :237-241): (R, M) token shares, a CPU tensor."""
+        alphas = [alphas] * M if isinstance(alphas, float) else alphas
+        if sample_tasks_uniformly:
+            return Dirichlet(self.sample_alphas(R, M, alphas=alphas)).sample()
+        return Dirichlet(torch.Tensor(alphas)).sample((R,))
+
     def generate_random_masks(self, input_tokens: Dict[str, torch.Tensor], num_encoded_tokens: int,
                               alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False):
         """Same random draws, in the same order and on the same devices, as the reference (:223-264); the integer
@@ -188,12 +195,16 @@ class MultiMAE(nn.Module):
         assert all(v.shape[1] == P for v in vals), "all modalities share one patch grid on this path"
         M = len(vals)
         R = B if self.per_sample_masks else 1
-        alphas = [alphas] * M if isinstance(alphas, float) else alphas
-        if sample_tasks_uniformly:
-            dist = Dirichlet(self.sample_alphas(R, M, alphas=alphas)).sample()
+        dist = getattr(self, "mask_draws", None)
+        if dist is not None:
+            # a captured step (pretrain.PretrainStep.capture): the host draws and copies into this static device tensor before each
+            # replay -- the draw itself cannot sit inside a hipGraph (host RNG, host->device copy)
+            assert dist.is_cuda and tuple(dist.shape) == (R, M)
         else:
-            dist = Dirichlet(torch.Tensor(alphas)).sample((R,))
-        if device.type == 'cuda' and ASYNC_DRAW_COPY:
+            dist = self.draw_mask_distribution(R, M, alphas, sample_tasks_uniformly)
+        if dist.is_cuda:
+            pass
+        elif device.type == 'cuda' and ASYNC_DRAW_COPY:
             # through pinned memory, asynchronously: a pageable host->device copy makes the host wait until the stream has drained,
             # i.e. one host/GPU synchronisation at the top of every step (the GPU then idles while the step's first launches arrive)
             dist = dist.pin_memory().to(device, non_blocking=True)

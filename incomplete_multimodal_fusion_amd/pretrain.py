@@ -275,6 +275,73 @@ class PretrainStep:
                     o = torch.zeros_like(v) if o is None else o          # first step skipped: back to the fresh state
                     v.copy_(torch.where(skip.to(v.device), o, v))
 
+    # -- the step as one hipGraph ------------------------------------------------------------------------------------------
+    def capture(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None, warmup: int = 2):
+        """Capture the whole step (forward, losses, backward, optimizer) on THESE input tensors into a hipGraph; afterwards
+        replay() runs it with one graph launch instead of ~2500 kernel launches from Python.  The step itself is unchanged -- the
+        same launches in the same order, bitwise the same results --, what goes away is the host's enqueue time (~30-45 ms a
+        step): that is the whole step at the small configurations (ViT-Small / 128 px: host-bound) and nothing at the headline
+        one (GPU-bound).  One process / one GPU, the flat engine, fixed shapes; new batches are COPIED into the captured input
+        tensors (`tasks_dict`'s, kept here) before a replay.  The host-side part of the mask draw (the Dirichlet shares) stays on
+        the host: replay() draws and copies them into a static device tensor first.  Eager calls must not be mixed in after
+        capture (the optimizer's device-side replay count would fall out of step with the host's count)."""
+        from .engine import FlatAdamW
+        if not isinstance(self.opt, FlatAdamW) or self.reducer is not None or self.balancer_opt is not None:
+            raise NotImplementedError("capture(): the flat engine, one rank, no companion optimizer")
+        if ops._TIMER is not None or ops._TIMERS or getattr(self.model, "layer_timer", None) is not None:
+            raise RuntimeError("capture(): switch the bench timers off first (HIP-event brackets cannot be captured)")
+        import torch.cuda.tunable as tun
+        tuning = tun.is_enabled() and tun.tuning_is_enabled()
+        self._x, self._masks = tasks_dict, task_masks
+        B = next(iter(tasks_dict.values())).shape[0]
+        M = len([d for d in self.in_domains if d in tasks_dict])
+        dev = next(iter(tasks_dict.values())).device
+        self._draw_shape = (B if self.model.per_sample_masks else 1, M)
+        self._draws = torch.empty(self._draw_shape, dtype=torch.float32, device=dev) if task_masks is None else None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # library handles, workspaces, TunableOp choices: settled before capture
+            for _ in range(max(1, warmup)):
+                self(tasks_dict, task_masks)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if tuning:
+            tun.tuning_enable(False)                         # an unseen shape must not start timing runs inside the capture
+        self.model.mask_draws = self._draws
+        self._next_draw()
+        self.opt.begin_capture()
+        graph = torch.cuda.CUDAGraph()
+        check = getattr(self.model, "check_masks", False)
+        self.model.check_masks = False                       # a host-side check of explicit masks: the warm-up steps ran it
+        try:
+            with torch.cuda.graph(graph):
+                self._static_out = self(tasks_dict, task_masks)
+        finally:
+            self.model.check_masks = check
+            self.opt.end_capture()
+            if tuning:
+                tun.tuning_enable(True)
+        self._graph = graph
+        return self
+
+    def _next_draw(self):
+        if self._draws is not None:
+            d = self.model.draw_mask_distribution(self._draw_shape[0], self._draw_shape[1], self.alphas, self.uniform)
+            self._draws.copy_(d.pin_memory(), non_blocking=True)
+
+    def replay(self, tasks_dict: Optional[Dict[str, torch.Tensor]] = None):
+        """One captured step.  tasks_dict: a new batch, copied into the captured input tensors (None: the tensors as they are).
+        Returns the captured step's result tensors (overwritten by the next replay)."""
+        if tasks_dict is not None and tasks_dict is not self._x:
+            for k, v in tasks_dict.items():
+                if k in self._x:
+                    self._x[k].copy_(v, non_blocking=True)
+        self._next_draw()
+        self.opt.replay_begin()
+        self._graph.replay()
+        self.opt.replay_end()
+        return self._static_out
+
     def __call__(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None):
         x = {t: v for t, v in tasks_dict.items() if t in self.in_domains}
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):

@@ -1,0 +1,88 @@
+"""The pretraining step captured into ONE hipGraph (PretrainStep.capture / replay): the same launches in the same order, so the replays
+must reproduce the eager steps bit for bit -- losses, weights, optimizer state --, including what a graph bakes in by value and the
+optimizer therefore reads from the device: the step count of the bias correction, the learning rate and the weight decay."""
+import copy
+
+import pytest
+import torch
+
+from tests.test_gpu_kernels import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=3):
+    from incomplete_multimodal_fusion_amd.pretrain import get_model
+    torch.manual_seed(seed)
+    base = get_model("small", input_size=128, decoder_dim=64, decoder_depth=1, decoder_num_heads=2)
+    base.depth = 2; base.blocks = base.blocks[:2]; base.fus_blocks = base.fus_blocks[:2]
+    B, P = 8, 64
+    x = {"s1": torch.randn(B, 1, 128, 128, device=DEV), "s2": torch.randn(B, 3, 128, 128, device=DEV),
+         "dem": torch.randn(B, 1, 128, 128, device=DEV)}
+    masks = {}
+    for d, k in (("s1", 40), ("s2", 30), ("dem", 26)):
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1).to(DEV)
+    return base, x, masks
+
+
+def _step(base, clip=None):
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    model = copy.deepcopy(base).to(DEV).train()
+    opt = FlatAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, exclude=model.never_used_parameters())
+    return model, opt, PretrainStep(model, opt, 96, clip_grad=clip, check_finite=True)
+
+
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_captured_step_replays_bitwise_like_eager(clip):
+    base, x, masks = _setup()
+    _, opt_e, step_e = _step(base, clip)
+    _, opt_g, step_g = _step(base, clip)
+    sched = [(1e-3, 0.05), (1e-3, 0.05), (7e-4, 0.05), (7e-4, 0.02), (2e-4, 0.0), (2e-4, 0.0)]   # (lr, weight decay) per step
+
+    def hyper(opt, i):
+        opt.param_groups[0]["lr"], opt.param_groups[0]["weight_decay"] = sched[i]
+    losses_e = []
+    for i in range(6):
+        hyper(opt_e, i)
+        losses_e.append(step_e(x, task_masks=masks)["loss"].clone())
+    hyper(opt_g, 0)                                   # capture() runs its two warm-up steps eagerly: steps 0 and 1 of the schedule
+    step_g.capture(x, masks, warmup=2)
+    assert opt_g.steps == 2
+    for i in range(2, 6):
+        hyper(opt_g, i)
+        out = step_g.replay()
+        assert torch.equal(out["loss"], losses_e[i]), (i, float(out["loss"]), float(losses_e[i]))
+    assert opt_g.steps == opt_e.steps == 6
+    assert torch.equal(opt_g.master, opt_e.master) and torch.equal(opt_g.exp_avg, opt_e.exp_avg)
+    assert torch.equal(opt_g.exp_avg_sq, opt_e.exp_avg_sq) and torch.equal(opt_g.shadow, opt_e.shadow)
+    assert not opt_g.last_step_skipped()
+
+
+def test_captured_step_takes_new_batches_and_fresh_mask_draws():
+    """Random masks: the Dirichlet shares are drawn on the host before every replay and reach the graph through a static device tensor;
+    a new batch is copied into the captured inputs.  The replays train (loss falls on a fixed batch) and differ from step to step."""
+    base, x, _ = _setup(5)
+    _, opt, step = _step(base)
+    step.capture(x, None)
+    first = float(step.replay()["loss"])
+    seen = set()
+    for _ in range(25):
+        out = step.replay()
+        seen.add(round(float(out["loss"]), 6))
+    assert len(seen) > 20                              # fresh masks every replay
+    assert float(out["loss"]) < first and torch.isfinite(out["loss"])
+    x2 = {k: v.flip(0).contiguous() for k, v in x.items()}
+    before = {k: v.clone() for k, v in x.items()}
+    step.replay(x2)
+    assert all(torch.equal(x[k], x2[k]) and not torch.equal(x[k], before[k]) for k in x)     # copied into the captured tensors
+
+
+def test_capture_refuses_what_it_cannot_hold():
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    base, x, masks = _setup()
+    model = copy.deepcopy(base).to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    with pytest.raises(NotImplementedError):
+        PretrainStep(model, opt, 96).capture(x, masks)
