@@ -434,7 +434,7 @@ def main():
                     help="main region: every sample draws its own mask row (packed variable-length segments)")
     ap.add_argument("--dropout", action="store_true", help="main region: random modality dropout (sample_tasks_uniformly: a "
                     "uniformly drawn non-empty modality subset per mask row, the others get no tokens)")
-    ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3; "
+    ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3,graph; "
                     "'auto' = both at N = 1 with default main settings, none otherwise; 'none'")
     ap.add_argument("--clip-grad", dest="clip_grad", type=float, default=0.0, help="> 0: device-side global-norm clipping")
     ap.add_argument("--block-timer", dest="block_timer", type=int, default=1, help="1: HIP-event brackets around encoder layer 6 "
@@ -544,7 +544,7 @@ def main():
     default_doms = args.domains == "s1,s2,dem" and args.fusion_blocks and args.contra == "dino"
     default_main = not (args.staging or args.per_sample or args.dropout or args.fp32) and default_doms
     dpdiag = dp_diagnostics(reducer, world, args.steps, ranks_dt, device, distributed)
-    legs = ("pcie,c3" if (world == 1 and default_main) else "") if args.legs == "auto" else \
+    legs = ("pcie,c3,graph" if (world == 1 and default_main) else "") if args.legs == "auto" else \
         ("" if args.legs == "none" else args.legs)
     legs = [l for l in legs.split(",") if l]
     leg_out = {}
@@ -572,6 +572,28 @@ def main():
                      "each modality dropped w.p. 1/2, never all), N=%d kept tokens per sample in variable-length packed "
                      "segments" % args.num_encoded_tokens,
             "loss": round(float(l3["loss"]), 4)}
+
+    if "graph" in legs and args.engine and not distributed:
+        # the same step as ONE hipGraph (PretrainStep.capture): one graph launch instead of ~2500 launches from Python.  Last leg:
+        # after capture the step must only be replayed.  The roofline timers cannot be captured (HIP-event brackets), so the
+        # headline region above stays eager; this leg shows what the host's enqueue time costs at this configuration.
+        try:
+            ops.set_kernel_timer(None)
+            model.layer_timer = None
+            t_cap = time.perf_counter()
+            resident_step.capture(x, None)
+            for _ in range(2):
+                resident_step.replay()
+            torch.cuda.synchronize()
+            t_cap = time.perf_counter() - t_cap
+            d4, l4, _, _ = timed_region(resident_step.replay, x, args.steps, distributed, device)
+            leg_out["graph_replay"] = {
+                "value": round(args.batch * world * args.steps / d4, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d4 / args.steps, 3),
+                "host_enqueue_ms_per_step": round(timed_region.host_enqueue_ms, 3), "capture_s": round(t_cap, 2),
+                "what": "the headline step captured into one hipGraph (forward, losses, backward, AdamW; mask shares drawn on the host "
+                        "before each replay), bitwise the eager step", "loss": round(float(l4["loss"]), 4)}
+        except Exception as e:                                   # never lose the headline line over the secondary leg
+            leg_out["graph_replay"] = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
