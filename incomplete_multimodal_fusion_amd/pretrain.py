@@ -329,13 +329,19 @@ class PretrainStep:
             d = self.model.draw_mask_distribution(self._draw_shape[0], self._draw_shape[1], self.alphas, self.uniform)
             self._draws.copy_(d.pin_memory(), non_blocking=True)
 
-    def replay(self, tasks_dict: Optional[Dict[str, torch.Tensor]] = None):
-        """One captured step.  tasks_dict: a new batch, copied into the captured input tensors (None: the tensors as they are).
-        Returns the captured step's result tensors (overwritten by the next replay)."""
+    def replay(self, tasks_dict: Optional[Dict[str, torch.Tensor]] = None, task_masks: Optional[Dict[str, torch.Tensor]] = None):
+        """One captured step.  tasks_dict / task_masks: a new batch / new explicit masks (only for a step captured WITH explicit
+        masks), copied into the captured tensors (None: the tensors as they are).  Returns the captured step's result tensors
+        (overwritten by the next replay)."""
         if tasks_dict is not None and tasks_dict is not self._x:
             for k, v in tasks_dict.items():
                 if k in self._x:
                     self._x[k].copy_(v, non_blocking=True)
+        if task_masks is not None and task_masks is not self._masks:
+            if self._masks is None:
+                raise ValueError("this step was captured with random masks")
+            for k, v in task_masks.items():
+                self._masks[k].copy_(v, non_blocking=True)
         self._next_draw()
         self.opt.replay_begin()
         self._graph.replay()

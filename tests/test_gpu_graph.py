@@ -58,6 +58,12 @@ def test_captured_step_replays_bitwise_like_eager(clip):
     assert torch.equal(opt_g.master, opt_e.master) and torch.equal(opt_g.exp_avg, opt_e.exp_avg)
     assert torch.equal(opt_g.exp_avg_sq, opt_e.exp_avg_sq) and torch.equal(opt_g.shadow, opt_e.shadow)
     assert not opt_g.last_step_skipped()
+    # new explicit masks are copied into the captured mask tensors: same result as the eager step on them
+    masks2 = {d: m.flip(1).contiguous() for d, m in masks.items()}
+    hyper(opt_e, 5); hyper(opt_g, 5)
+    le = step_e(x, task_masks=masks2)["loss"]
+    lg = step_g.replay(None, masks2)["loss"]
+    assert torch.equal(le, lg) and torch.equal(opt_g.master, opt_e.master)
 
 
 def test_captured_step_takes_new_batches_and_fresh_mask_draws():
