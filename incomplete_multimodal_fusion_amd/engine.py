@@ -51,6 +51,7 @@ class FlatAdamW:
         self._ctl = torch.zeros(8, dtype=torch.float32, device=dev)
         self._capturing = False            # step() is being captured into a hipGraph (begin_capture / end_capture)
         self._graph_lr = None              # (learning rate, weight decay) last written to _ctl[5:7]
+        self._graph_params: List[torch.nn.Parameter] = []     # the parameters the captured step updates
         self._ctl_used = False
         self._pstep: Dict[int, int] = {id(p): 0 for p in self.params}    # per-parameter step counts, as torch keeps them
         self._in_place = set()             # ids of weights whose gradient a producer wrote in place since zero_grad()
@@ -213,10 +214,11 @@ class FlatAdamW:
                      float(g["weight_decay"]), st, float(grad_scale), stream())
         if ctl:
             absent = [p for p in self.params if p.grad is None]
-            if self._capturing and absent:
-                raise RuntimeError("a captured step needs every parameter of the engine to receive a gradient (exclude the rest: "
-                                   "FlatAdamW(..., exclude=model.never_used_parameters()))")
-            if absent and self.last_step_skipped():
+            if self._capturing:
+                # a graph is static: the parameters without a gradient now have none in any replay and are never updated (what
+                # the eager step does for them, step by step); their step counts stay where they are
+                self._graph_params = [p for p in self.params if p.grad is not None]
+            elif absent and self.last_step_skipped():
                 # the kernels bias-correct with (host count - skipped steps so far); a parameter that sat this skipped step
                 # out must not lose a step for it.  Host sync, only when the set of used parameters varies (downstream).
                 for p in absent:
@@ -225,10 +227,11 @@ class FlatAdamW:
 
     # -- hipGraph capture of the step (pretrain.PretrainStep.capture) ---------------------------------------------------
     def begin_capture(self):
-        """The following step() is being captured: it always takes the device-controlled path, reads its step counts and
-        learning rate through the control block (the captured launches keep their by-value arguments) and needs a gradient for
-        every parameter.  After end_capture() use replay_begin() / replay_end() around each graph replay; eager step() calls must
-        not be mixed in any more (the device's replay count would no longer match the host's step count)."""
+        """The following step() is being captured: it always takes the device-controlled path and reads its step counts, learning
+        rate and weight decay through the control block (the captured launches keep their by-value arguments).  A graph is static:
+        the parameters without a gradient at capture time are never updated by the replays.  After end_capture() use
+        replay_begin() / replay_end() around each graph replay; eager step() calls must not be mixed in any more (the device's
+        replay count would no longer match the host's step count)."""
         self._capturing = True
         self._ctl[4:8].zero_()
         self._graph_lr = None
@@ -237,7 +240,7 @@ class FlatAdamW:
         """The captured step() only recorded launches: take back the host-side counts it advanced."""
         self._capturing = False
         self.steps -= 1
-        for p in self.params:
+        for p in self._graph_params:
             self._pstep[id(p)] -= 1
 
     def replay_begin(self):
@@ -251,7 +254,7 @@ class FlatAdamW:
     def replay_end(self):
         """After a graph replay: the host's view of the step counts."""
         self.steps += 1
-        for p in self.params:
+        for p in self._graph_params:
             self._pstep[id(p)] += 1
 
     def skip_flag(self) -> Optional[torch.Tensor]:
