@@ -349,6 +349,9 @@ class PretrainStep:
         return self._static_out
 
     def __call__(self, tasks_dict: Dict[str, torch.Tensor], task_masks: Optional[Dict[str, torch.Tensor]] = None):
+        if getattr(self, "_graph", None) is not None:
+            raise RuntimeError("this step has been captured into a hipGraph: use replay() (an eager step would reuse the static mask "
+                               "shares and put the optimizer's device-side replay count out of step with the host's)")
         x = {t: v for t, v in tasks_dict.items() if t in self.in_domains}
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             out = self.model(x, task_masks=task_masks, num_encoded_tokens=self.N, alphas=self.alphas,

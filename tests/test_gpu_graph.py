@@ -79,6 +79,8 @@ def test_captured_step_takes_new_batches_and_fresh_mask_draws():
         seen.add(round(float(out["loss"]), 6))
     assert len(seen) > 20                              # fresh masks every replay
     assert float(out["loss"]) < first and torch.isfinite(out["loss"])
+    with pytest.raises(RuntimeError):
+        step(x)                                        # eager calls are refused once the step is a graph
     x2 = {k: v.flip(0).contiguous() for k, v in x.items()}
     before = {k: v.clone() for k, v in x.items()}
     step.replay(x2)
