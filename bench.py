@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")   # newest committed rocprofv3 summaries first
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")   # newest committed rocprofv3 summaries first
 
 
 # ---------------------------------------------------------------------------------------------------------- launcher
@@ -526,7 +526,8 @@ def main():
     prof_ln = ops.KernelTimer("mmae_add_ln_bwd")
     prof_ln.every = 3                         # 59 launches per step of the timed instance: every 3rd (rows alternate, 59 is odd: all shapes)
     prof_gemm = ops.KernelTimer("mmae_gemm_nt")
-    prof_gemm.every = 7                       # 182 launches per step: every 7th is bracketed (26 per step, all shapes in rotation)
+    prof_gemm.every = 11                      # 182 = 2 x 7 x 13 launches per step: a stride CO-PRIME to it visits every launch position of the
+                                              # step once per 11 steps (round 4's every-7th was phase-locked: the same 26 launches each step)
     for _ in range(args.warmup):
         losses = step(x)
     ops.set_kernel_timer([prof, prof_ln, prof_gemm])
@@ -623,9 +624,12 @@ def main():
                        "inputs": "host, PCIe inclusive" if args.staging else "resident in HBM",
                        "trainable_params": n_params, "loss": round(loss_val, 4)},
             "ranks": world, "backend": (dist.get_backend() if distributed else "none"),
-            # dominant hand-written kernel by total time (profiles/rNN_kernel_stats.md): the fused residual-add +
-            # double-LayerNorm backward, HBM-bound.  achieved = algorithmic bytes of the launch / its HIP-event time.
-            "roofline": {"kernel": "add_ln_bwd_fast_kernel<bf16,bf16,3,double,up,gx,gdelta>" if not args.fp32 else "add_ln_bwd_fast_kernel<f32,...>",
+            # the dominant kernel of the step by total time (profiles/rNN_kernel_stats.md): the own persistent GEMM gemm8p_kernel<0> (every
+            # forward / input-gradient projection of the encoder), MFMA-bound.  Filled in below from the live HIP-event brackets.
+            "roofline": None,
+            # dominant HBM-bound hand-written kernel: the fused residual-add + double-LayerNorm backward.
+            # achieved = algorithmic bytes of the launch / its HIP-event time.
+            "roofline_hbm": {"kernel": "add_ln_bwd_fast_kernel<bf16,bf16,3,double,up,gx,gdelta>" if not args.fp32 else "add_ln_bwd_fast_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (replay_ok and hbm_ok) else None,
@@ -669,17 +673,25 @@ def main():
                                      "achieved": round(ach_b, 1), "frac": round(ach_b / MFMA_BF16_PEAK_TF, 4),
                                      "achieved_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12, 1) if tot_ms > 0 else 0.0,
                                      "frac_reference_dense": round(args.batch * ldense / (tot_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if tot_ms > 0 else 0.0}
-        # the dominant kernel of the step BY TIME: the own persistent GEMM (csrc/gemm.hip, gemm8p_kernel<0>: every forward / input-gradient
-        # projection of the encoder), measured live -- HIP events around every 7th launch on the stream it runs on, 2 M N K FLOPs each
+        # `roofline`: the dominant kernel of the step BY TIME -- the own persistent GEMM (csrc/gemm.hip, gemm8p_kernel<0>: every forward /
+        # input-gradient projection of the encoder) -- measured live: HIP events on the stream it runs on around every 11th launch of
+        # mmae_gemm_nt (11 is co-prime to the 182 launches of a step, so over the timed region every launch position -- every shape --
+        # is sampled equally often), algorithmic FLOPs 2 M N K of exactly the bracketed launches.  The committed rocprofv3 summary of
+        # this command (profiles/rNN_kernel_stats.md) must agree: FLOPs per step / its ms per step for this kernel.
         g_raw, g_n, g_fl = prof_gemm.summary()
         if g_n:
             g_ms = max(g_raw - ev_ms, 1e-6)
             g_tf = g_fl / g_n / (g_ms * 1e-3) / 1e12
-            out["roofline_gemm_own"] = {"kernel": "gemm8p_kernel<0> (own persistent 256x256x64 8-phase GEMM: forward + input-gradient projections)",
-                                        "bound": "mfma", "achieved": round(g_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                                        "frac": round(g_tf / MFMA_BF16_PEAK_TF, 4), "avg_launch_ms": round(g_ms, 4),
-                                        "avg_flops_per_launch": round(g_fl / g_n), "bracketed_launches": g_n,
-                                        "sampling": "every 7th launch of mmae_gemm_nt", "event_bracket_overhead_ms": round(ev_ms, 4)}
+            out["roofline"] = {"kernel": "gemm8p_kernel<0> (own persistent 256x256x64 8-phase bf16 GEMM: forward + input-gradient projections)",
+                               "bound": "mfma", "achieved": round(g_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(g_tf / MFMA_BF16_PEAK_TF, 4),
+                               "traffic": pmc_traffic("gemm8p_kernel<0>") if (replay_ok and hbm_ok) else None,
+                               "algorithmic_flops_per_launch": round(g_fl / g_n), "avg_launch_ms": round(g_ms, 4),
+                               "avg_bracket_ms": round(g_raw, 4), "event_bracket_overhead_ms": round(ev_ms, 4),
+                               "launches": g_n, "launches_per_step": round(prof_gemm.seen / max(args.steps, 1), 1),
+                               "sampling": "every 11th launch of mmae_gemm_nt (stride co-prime to the launches per step)"}
+        else:                                      # configurations the own GEMM does not serve (fp32, small batches): the HBM leg is the line's roofline
+            out["roofline"] = out["roofline_hbm"]
         if replay_ok:
             # replayed (not measured in this process): null when the profiled step no longer matches this run
             rg = gemm_roofline()
@@ -688,7 +700,7 @@ def main():
             out["mfma_busy_pct"] = mb["pct"] if (mb is not None and sq_ok) else None
             out["mfma_busy_source"] = mb["source"] if mb is not None else None
             out["replayed_from"] = {"sq_step": rep_sq, "pmc_hbm": rep_hbm,
-                                    "fields": "mfma_busy_pct, roofline_gemm <- sq_step; roofline.traffic, roofline_attention.traffic <- pmc_hbm"}
+                                    "fields": "mfma_busy_pct, roofline_gemm <- sq_step; roofline.traffic, roofline_hbm.traffic, roofline_attention.traffic <- pmc_hbm"}
         out.update(dpdiag)
         out.update(leg_out)
         if world == 1 and not args.no_cpu_baseline:

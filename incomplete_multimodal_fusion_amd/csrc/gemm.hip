@@ -27,6 +27,7 @@
 //   epilogue's stores (too low a count only waits longer, too high a count would read a tile early).
 #include "common.hpp"
 #include "mmae_hip.h"
+#include <atomic>
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -317,13 +318,23 @@ bool gemm_shape_ok(long M, long N, long K, long lda, long ldw, long ldc, long wr
     return mpad * lda * 2 < (1L << 31) && wrows * ldw * 2 < (1L << 31) && mpad * ldc * 2 < (1L << 31);      // (int offset arithmetic in the kernel)
 }
 
+// The opt-in to more than 64 KB of dynamic LDS is a PER-DEVICE function attribute: set once per (kernel, device) -- a process that drives
+// several GPUs launches on each of them -- behind an atomic flag (racing threads set the same value twice at worst).
+template <typename K>
+bool gm_lds_opt_in(K kernel, int bytes, std::atomic<bool> (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!done[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        done[dev].store(true, std::memory_order_release);
+    }
+    return true;
+}
+
 template <int EPI>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    static bool attr_set = false;                            // (idempotent; racing threads set the same value)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return MMAE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<bool> attr_set[64];
+    if (!gm_lds_opt_in(gemm8p_kernel<EPI>, 131072, attr_set)) return MMAE_ERR_LAUNCH;
     const long tiles = (long)a.ntm * a.ntn;
     const int nper = tiles >= 256 ? 32 : (int)((tiles + 7) / 8);          // workgroups per XCD group; one workgroup per CU (128 KB of LDS)
     MMAE_LAUNCH((gemm8p_kernel<EPI>), dim3(8 * nper), dim3(512), 131072, st, a);
@@ -586,11 +597,8 @@ extern "C" int mmae_gemm_tn(long rows, long N, long Kin, const void* G, long ldg
     if ((reinterpret_cast<uintptr_t>(G) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return MMAE_ERR_ARG;
     if (pl.S > 1 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 15))) return MMAE_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_tn8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return MMAE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<bool> attr_set[64];
+    if (!gm_lds_opt_in(gemm_tn8p_kernel, 163840, attr_set)) return MMAE_ERR_LAUNCH;
     TnArgs a{};
     a.G = (const bf16*)G; a.X = (const bf16*)X; a.P = pl.S > 1 ? ws : out;
     a.rows = (int)rows; a.N = (int)N; a.Kin = (int)Kin; a.ldg = (int)ldg; a.ldx = (int)ldx;

@@ -52,6 +52,8 @@ class FlatAdamW:
         self._capturing = False            # step() is being captured into a hipGraph (begin_capture / end_capture)
         self._graph_lr = None              # (learning rate, weight decay) last written to _ctl[5:7]
         self._graph_params: List[torch.nn.Parameter] = []     # the parameters the captured step updates
+        self._graph_base: Dict[int, int] = {}                 # their step counts as baked into the captured launches (count BEFORE the captured step)
+        self._stepped_in_capture = False
         self._ctl_used = False
         self._pstep: Dict[int, int] = {id(p): 0 for p in self.params}    # per-parameter step counts, as torch keeps them
         self._in_place = set()             # ids of weights whose gradient a producer wrote in place since zero_grad()
@@ -97,7 +99,15 @@ class FlatAdamW:
         for p in ps:
             p.grad = p._mmae_grad
 
+    def _flush_deferred(self):
+        """Backstop: weight-gradient sums still queued by ops._wgrad (normally run and published by the end-of-backward callback,
+        which autograd skips when backward() raised) are summed and published before the gradients are read."""
+        from . import ops
+        ops.flush_splitk()
+
     def zero_grad(self, set_to_none: bool = True):
+        from . import ops
+        ops.reset_splitk()                 # deferred split-K sums a FAILED backward left queued must not be summed into this pass's buffer
         self._pending.clear()
         self._in_place.clear()
         for p in self.params:
@@ -107,6 +117,7 @@ class FlatAdamW:
     def grad_norm(self) -> torch.Tensor:
         """L2 norm over the flat gradient buffer (a parameter without a gradient contributes its zero-filled range, like
         get_grad_norm_ skipping it, native_scaler.py:49-62).  Device scalar, no host sync."""
+        self._flush_deferred()
         self.flush()
         call("mmae_grad_norm", self.n, ptr(self.grads), ptr(self._ws), ptr(self._norm), stream())
         return self._norm[0]
@@ -181,8 +192,10 @@ class FlatAdamW:
         reference).  All three are decided on the device from mmae_grad_norm's result -- no host synchronisation; see
         last_step_skipped() / last_grad_norm() to read the outcome."""
         g = self.param_groups[0]
+        self._flush_deferred()
         self.flush()
         self.steps += 1
+        self._stepped_in_capture = self._capturing
         ctl = clip_grad is not None or skip_grad is not None or check_finite or self._capturing
         if self._capturing:
             # the launches below are replayed with THESE by-value arguments: the replay count the device keeps is added to the
@@ -218,6 +231,7 @@ class FlatAdamW:
                 # a graph is static: the parameters without a gradient now have none in any replay and are never updated (what
                 # the eager step does for them, step by step); their step counts stay where they are
                 self._graph_params = [p for p in self.params if p.grad is not None]
+                self._graph_base = {id(p): self._pstep[id(p)] - 1 for p in self._graph_params}
             elif absent and self.last_step_skipped():
                 # the kernels bias-correct with (host count - skipped steps so far); a parameter that sat this skipped step
                 # out must not lose a step for it.  Host sync, only when the set of used parameters varies (downstream).
@@ -233,12 +247,17 @@ class FlatAdamW:
         replay_begin() / replay_end() around each graph replay; eager step() calls must not be mixed in any more (the device's
         replay count would no longer match the host's step count)."""
         self._capturing = True
+        self._stepped_in_capture = False
         self._ctl[4:8].zero_()
         self._graph_lr = None
 
     def end_capture(self):
-        """The captured step() only recorded launches: take back the host-side counts it advanced."""
+        """The captured step() only recorded launches: take back the host-side counts it advanced -- if it ran at all (a capture
+        that raised before reaching step() has advanced nothing)."""
         self._capturing = False
+        if not self._stepped_in_capture:
+            return
+        self._stepped_in_capture = False
         self.steps -= 1
         for p in self._graph_params:
             self._pstep[id(p)] -= 1
@@ -290,16 +309,30 @@ class FlatAdamW:
         self.steps = int(sd["steps"])
         ps = sd.get("param_steps") or [self.steps] * len(self.params)
         self._pstep = {id(p): int(st) for p, st in zip(self.params, ps)}
-        self._ctl.zero_()
+        self._counts_restored()
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.refresh_shadow()
+
+    def _counts_restored(self):
+        """The host's step counts were replaced (checkpoint resume): the device's control block must describe the SAME counts.
+        Multiplier / skip flag / skipped-step count / norm start over (the restored counts are net of skipped steps).  A captured
+        step keeps its by-value step counts (those of capture time): the replay counter the kernels add to them is set so that
+        the next replay bias-corrects with restored count + 1, and the learning rate / weight decay are handed over again."""
+        self._ctl[0:4].zero_()
+        if self._graph_params:
+            d = {self._pstep[id(p)] - self._graph_base[id(p)] for p in self._graph_params}
+            if len(d) != 1:
+                raise RuntimeError("resuming into a captured step: the restored per-parameter step counts are not a uniform shift of the "
+                                   "captured ones -- capture() the step again after loading")
+            self._ctl[4:5].fill_(float(d.pop()))
+            self._graph_lr = None
 
     def set_param_steps(self, steps: Dict[int, int]):
         """{id(parameter): step count}: restores torch-layout optimizer state (checkpoint.load_optimizer_state_dict)."""
         for p in self.params:
             self._pstep[id(p)] = int(steps.get(id(p), 0))
         self.steps = max(self._pstep.values()) if self._pstep else 0
-        self._ctl.zero_()
+        self._counts_restored()
 
 
 def shadow_of(ws, dtype) -> Optional[torch.Tensor]:

@@ -44,12 +44,13 @@ class KernelTimer:
 
     def __init__(self, name: str):
         self.name, self.pairs, self.flops, self.kernels = name, [], None, set()      # kernels: device kernel names the launches ran
+        self.seen, self.every = 0, 1
 
     def sample(self) -> bool:
         """True for every `every`-th call (default: each one): a bracket costs the stream ~5 us of idle time per event, so a
         timer on an entry point with many launches per step brackets a rotating subset."""
-        self.seen = getattr(self, "seen", 0) + 1
-        return self.seen % getattr(self, "every", 1) == 0
+        self.seen += 1
+        return self.seen % self.every == 0
 
     def bracket(self):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -203,20 +204,49 @@ OWN_GEMM = 1          # bit 0: forward / input-gradient projections of supported
                       # rate, no change from 3 to 5 staging steps in flight), +4.7 ms in the step -> OFF by default.
                       # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
 _OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
+CALLS = {"mmae_gemm_nt": 0, "mmae_gemm_geglu": 0, "mmae_gemm_tn": 0}     # launches of the own GEMM entry points (tests assert engagement)
 
 
-def own_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+_WARNED = set()
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import sys
+        print("[mmae] " + msg, file=sys.stderr, flush=True)
+
+
+def _offset_limit_note(kind, M, N, K, ld_in, ld_out):
+    """The own GEMM addresses its operands with 31-bit byte offsets (csrc/gemm.hip gemm_shape_ok); a projection that is big enough for
+    it but exceeds that range falls back to the library GEMM -- say so once per shape instead of silently (a slower path, not an error)."""
+    mpad = (M + 255) // 256 * 256
+    if mpad * ld_in * 2 >= (1 << 31) or mpad * ld_out * 2 >= (1 << 31):
+        _warn_once((kind, M, N, K), "%s M=%d N=%d K=%d: operand larger than the own GEMM's 31-bit byte offsets -> library GEMM for this "
+                   "shape (smaller per-GPU batch or row chunks keep it on the own kernel)" % (kind, M, N, K))
+
+
+def own_gemm_ok(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> bool:
     """Can y = x @ w^T run on mmae_gemm_nt?  x (M, K), w (N, K): bf16, unit column stride, 16-byte aligned bases, N % 256 == 0,
-    K % 128 == 0, K >= 384, and enough tiles to fill the 256 persistent workgroups."""
+    K % 128 == 0, K >= 384, and enough tiles to fill the 256 persistent workgroups.  out: the destination the caller wants written
+    (a row-slice view of a larger matrix, say): its row stride and base alignment are part of the answer."""
     if not (OWN_GEMM & 1) or x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or not x.is_cuda:
         return False
     M, K = x.shape
     N = w.shape[0]
     if w.shape[1] != K or x.stride(1) != 1 or w.stride(1) != 1 or x.data_ptr() % 16 or w.data_ptr() % 16:
         return False
+    ldc = N
+    if out is not None:
+        if out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1 or out.data_ptr() % 8:
+            return False
+        ldc = out.stride(0)
     if ((M + 255) // 256) * (N // 256) < _OWN_GEMM_MIN_TILES:
         return False
-    return bool(_lib.lib().mmae_gemm_nt_supported(M, N, K, x.stride(0), w.stride(0), N))
+    ok = bool(_lib.lib().mmae_gemm_nt_supported(M, N, K, x.stride(0), w.stride(0), ldc))
+    if not ok and N % 256 == 0 and K % 128 == 0 and K >= 384:
+        _offset_limit_note("gemm_nt", M, N, K, x.stride(0), ldc)
+    return ok
 
 
 def gemm_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -225,13 +255,14 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if out is None else out
     assert y.shape == (M, N) and y.stride(1) == 1 and y.dtype == torch.bfloat16
-    tm = _TIMERS.get("mmae_gemm_nt")            # bench.py's roofline_gemm: every `every`-th launch is bracketed (a bracket costs ~5 us)
+    tm = _TIMERS.get("mmae_gemm_nt")            # bench.py's roofline: every `every`-th launch is bracketed (a bracket costs ~5 us)
     if tm is not None and not tm.sample():
         tm = None
     if tm is not None:
         tm.add_flops(2.0 * M * N * K)
         ev0, ev1 = tm.bracket()
         ev0.record()
+    CALLS["mmae_gemm_nt"] += 1
     call("mmae_gemm_nt", M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(y), y.stride(0), stream())
     if tm is not None:
         ev1.record()
@@ -240,14 +271,14 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None
 
 def matmul_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ w^T: the own kernel where it applies, the library GEMM (hipBLASLt through torch) otherwise."""
-    if own_gemm_ok(x, w):
+    if own_gemm_ok(x, w, out):
         return gemm_nt(x, w, out)
     if out is not None:
         return torch.mm(x, w.t(), out=out)
     return torch.nn.functional.linear(x, w)
 
 
-def own_geglu_ok(y: torch.Tensor, w1: torch.Tensor) -> bool:
+def own_geglu_ok(y: torch.Tensor, w1: torch.Tensor, h: Optional[torch.Tensor] = None, g: Optional[torch.Tensor] = None) -> bool:
     if not (OWN_GEMM & 1) or y.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or y.dim() != 2 or not y.is_cuda:
         return False
     M, K = y.shape
@@ -257,7 +288,16 @@ def own_geglu_ok(y: torch.Tensor, w1: torch.Tensor) -> bool:
     F = F2 // 2
     if ((M + 255) // 256) * (F // 128) < _OWN_GEMM_MIN_TILES:
         return False
-    return bool(_lib.lib().mmae_gemm_geglu_supported(M, F, K, y.stride(0), w1.stride(0), 2 * F, F))
+    ldh, ldg = 2 * F, F
+    for t, width in ((h, 2 * F), (g, F)):
+        if t is not None and (t.dtype != torch.bfloat16 or t.shape != (M, width) or t.stride(1) != 1 or t.data_ptr() % 4):
+            return False
+    ldh = h.stride(0) if h is not None else ldh
+    ldg = g.stride(0) if g is not None else ldg
+    ok = bool(_lib.lib().mmae_gemm_geglu_supported(M, F, K, y.stride(0), w1.stride(0), ldh, ldg))
+    if not ok and F % 128 == 0 and K % 128 == 0 and K >= 384:
+        _offset_limit_note("gemm_geglu", M, F, K, y.stride(0), ldh)
+    return ok
 
 
 def gemm_geglu(y: torch.Tensor, w1: torch.Tensor, h: torch.Tensor, g: torch.Tensor):
@@ -265,6 +305,7 @@ def gemm_geglu(y: torch.Tensor, w1: torch.Tensor, h: torch.Tensor, g: torch.Tens
     M, K = y.shape
     F = w1.shape[0] // 2
     assert h.shape == (M, 2 * F) and g.shape == (M, F) and h.stride(1) == 1 and g.stride(1) == 1
+    CALLS["mmae_gemm_geglu"] += 1
     call("mmae_gemm_geglu", M, F, K, ptr(y), y.stride(0), ptr(w1), w1.stride(0), ptr(h), h.stride(0), ptr(g), g.stride(0), stream())
 
 
@@ -381,6 +422,7 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
     assert out.shape == (n_out, n_in) and out.is_contiguous() and out.dtype == torch.float32
     nws = _lib.lib().mmae_gemm_tn_ws_floats(rows, n_out, n_in)
     ws = torch.empty(nws, dtype=torch.float32, device=g2.device) if nws else None
+    CALLS["mmae_gemm_tn"] += 1
     call("mmae_gemm_tn", rows, n_out, n_in, ptr(g2), g2.stride(0), ptr(x2), x2.stride(0), ptr(out), ptr(ws), stream())
     return out
 
@@ -391,9 +433,16 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
 # The gradient is PUBLISHED (engine.grads_written_in_place: .grad set, DP reducer told) by the flush, after the launch that completes it,
 # so its only consumers -- optimizer step and gradient all-reduce -- stay ordered behind it on the stream.  ~140 dependent 6-us launches
 # per step become ~15.  (A gradient that autograd itself consumes is never deferred: its consumer kernel is enqueued at once.)
+# No sticky state: the end-of-backward callback is queued whenever the queue goes from empty to non-empty (a backward pass that raised
+# never ran its callbacks; the next pass registers its own), and engine.FlatAdamW.zero_grad() drops whatever a failed pass left queued
+# (reset_splitk) while step() / grad_norm() flush as a backstop.
 DEFER_SPLITK = True
 _SPLITK_Q = []                 # (partials, S, n, out view, weights to publish)
-_SPLITK_CB = [False]
+
+
+def reset_splitk():
+    """Drop queued split-K sums without running them (their backward pass failed: engine.FlatAdamW.zero_grad)."""
+    _SPLITK_Q.clear()
 
 
 def flush_splitk():
@@ -416,7 +465,6 @@ def flush_splitk():
 
 
 def _end_of_backward_flush():
-    _SPLITK_CB[0] = False
     flush_splitk()
 
 
@@ -439,10 +487,9 @@ def _wgrad(g2, x2, gview, publish=None):
         if part.dtype == torch.bfloat16 and (n_out * n_in) % 8 == 0:
             out = gview if gview is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device)
             if publish is not None and gview is not None and DEFER_SPLITK and _lib.raw_stream() == 0:      # the default stream
-                _SPLITK_Q.append((part, S, n_out * n_in, out, publish))
-                if not _SPLITK_CB[0]:
-                    _SPLITK_CB[0] = True
+                if not _SPLITK_Q:       # empty -> non-empty: this backward pass flushes at its end (a few per pass: _KvQ flushes per layer)
                     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_flush)
+                _SPLITK_Q.append((part, S, n_out * n_in, out, publish))
                 return out
             call("mmae_splitk_sum", S, n_out * n_in, ptr(part), ptr(out), stream())
             return done(out)
@@ -1076,7 +1123,7 @@ class _FeedForwardGEGLU(torch.autograd.Function):
         f = torch.empty(rows, w2.shape[0], dtype=T, device=y.device)
         with _NoAutocast():
             for a, b in _row_chunks(rows, FF_CHUNKS):
-                if own_geglu_ok(y[a:b], w1c):
+                if own_geglu_ok(y[a:b], w1c, h[a:b], g[a:b]):
                     gemm_geglu(y[a:b], w1c, h[a:b], g[a:b])         # FeedForward[1] + GEGLU in one kernel (csrc/gemm.hip)
                 else:
                     matmul_nt(y[a:b], w1c, out=h[a:b])

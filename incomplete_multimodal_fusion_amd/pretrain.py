@@ -281,7 +281,10 @@ class PretrainStep:
         replay() runs it with one graph launch instead of ~2500 kernel launches from Python.  The step itself is unchanged -- the
         same launches in the same order, bitwise the same results --, what goes away is the host's enqueue time (~30-45 ms a
         step): that is the whole step at the small configurations (ViT-Small / 128 px: host-bound) and nothing at the headline
-        one (GPU-bound).  One process / one GPU, the flat engine, fixed shapes; new batches are COPIED into the captured input
+        one (GPU-bound).
+        The `warmup` steps that precede the capture are REAL training steps on `tasks_dict` (optimizer updates at the learning
+        rate of the moment, step counts advanced): a schedule that starts after capture() starts at step `warmup`.  A step can be
+        captured once; a failed capture leaves the step eager and unchanged.  One process / one GPU, the flat engine, fixed shapes; new batches are COPIED into the captured input
         tensors (`tasks_dict`'s, kept here) before a replay.  The host-side part of the mask draw (the Dirichlet shares) stays on
         the host: replay() draws and copies them into a static device tensor first.  Eager calls must not be mixed in after
         capture (the optimizer's device-side replay count would fall out of step with the host's count)."""
@@ -290,6 +293,8 @@ class PretrainStep:
             raise NotImplementedError("capture(): the flat engine, one rank, no companion optimizer")
         if ops._TIMER is not None or ops._TIMERS or getattr(self.model, "layer_timer", None) is not None:
             raise RuntimeError("capture(): switch the bench timers off first (HIP-event brackets cannot be captured)")
+        if getattr(self, "_graph", None) is not None:
+            raise RuntimeError("capture(): this step is already captured -- build a new PretrainStep to capture again")
         import torch.cuda.tunable as tun
         tuning = tun.is_enabled() and tun.tuning_is_enabled()
         self._x, self._masks = tasks_dict, task_masks
@@ -316,9 +321,15 @@ class PretrainStep:
         try:
             with torch.cuda.graph(graph):
                 self._static_out = self(tasks_dict, task_masks)
+        except BaseException:
+            # the step stays eager: back to fresh mask draws per call (not the one static share), nothing captured
+            self.model.mask_draws = None
+            self._draws = None
+            self._graph = None
+            raise
         finally:
             self.model.check_masks = check
-            self.opt.end_capture()
+            self.opt.end_capture()                           # (takes the step counts back only if the captured step() ran)
             if tuning:
                 tun.tuning_enable(True)
         self._graph = graph

@@ -125,15 +125,68 @@ def per_sample_oracle(state, x, masks, N, heads, dec_heads, bf16=False, domains=
     return {k: v.detach().double().cpu() for k, v in flat.items()}
 
 
-def native_step_flat(model, x, masks, N, autocast, fused=True, contra="dino", domains=O.DOMAINS, patch=16):
+class own_gemm_engaged:
+    """`with parity.own_gemm_engaged(): ...` -- the composition bench.py runs, at test sizes: every projection whose SHAPE the own
+    GEMM supports goes to it (ops._OWN_GEMM_MIN_TILES = 0; the product threshold of 512 tiles keeps B <= 8 steps on the library GEMM),
+    and on exit the context asserts that mmae_gemm_nt (and, when `geglu`, mmae_gemm_geglu) were actually launched.  min_tiles=None
+    keeps the product threshold (the B = 64 step at default dispatch)."""
+
+    def __init__(self, geglu=True, min_tiles=0):
+        self.geglu, self.min_tiles = geglu, min_tiles
+
+    def __enter__(self):
+        from incomplete_multimodal_fusion_amd import ops
+        self.ops, self.saved = ops, ops._OWN_GEMM_MIN_TILES
+        if self.min_tiles is not None:
+            ops._OWN_GEMM_MIN_TILES = self.min_tiles
+        self.before = dict(ops.CALLS)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.ops._OWN_GEMM_MIN_TILES = self.saved
+        self.calls = {k: self.ops.CALLS[k] - self.before[k] for k in self.before}
+        if et is None:
+            assert self.calls["mmae_gemm_nt"] > 0, "the own GEMM was not engaged: %s" % self.calls
+            assert not self.geglu or self.calls["mmae_gemm_geglu"] > 0, "the own FF1+GEGLU GEMM was not engaged: %s" % self.calls
+        return False
+
+
+def native_step_flat(model, x, masks, N, autocast, fused=True, contra="dino", domains=O.DOMAINS, patch=16, engine=False):
+    """One native step -> flat result dict.  engine=True: through engine.FlatAdamW exactly as PretrainStep / bench.py run it -- GEMM
+    weights read from the engine's bf16 shadows, input gradients through its TRANSPOSED shadows, Linear weight gradients written
+    in place into the flat fp32 buffer (deferred split-K sums included) -- and the gradients are read back FROM THE FLAT BUFFER."""
+    from incomplete_multimodal_fusion_amd import ops
     from incomplete_multimodal_fusion_amd.pretrain import step_losses
     model.fuse_unpatchify_loss = fused
-    model.zero_grad(set_to_none=True)
+    opt = None
+    if engine:
+        from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+        opt = getattr(model, "_parity_engine", None)
+        if opt is None:
+            opt = model._parity_engine = FlatAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05,
+                                                   exclude=model.never_used_parameters())
+    else:
+        model.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         out = model(x, task_masks=masks, num_encoded_tokens=N)
         losses = step_losses(out, x, masks, patch_size=patch, contra=contra)
+    if opt is not None:
+        opt.zero_grad()                                   # PretrainStep's order: forward, zero_grad, backward
     losses[2].backward()
-    return flatten_step(out, losses, {n: p.grad for n, p in model.named_parameters()}, domains)
+    if opt is None:
+        grads = {n: p.grad for n, p in model.named_parameters()}
+    else:
+        ops.join_wgrad_stream()
+        opt.grad_norm()                                   # what step() does first: deferred split-K sums + pending small gradients -> flat buffer
+        held = {id(p) for p in opt.params}
+        grads = {}
+        for n, p in model.named_parameters():
+            if id(p) in held:
+                assert p.grad is None or p.grad.data_ptr() == p._mmae_grad.data_ptr(), n + ": gradient not in the flat buffer"
+                grads[n] = p._mmae_grad.detach().clone() if p.grad is not None else None
+            else:
+                grads[n] = p.grad
+    return flatten_step(out, losses, grads, domains)
 
 
 def _maxrel(a, b):

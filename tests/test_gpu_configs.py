@@ -43,11 +43,17 @@ def _full_step(model, heads, B, size, keep, mode):
     masks = _masks(P, B, keep)
     N = sum(keep.values())
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    autocast = mode == "bf16"
+    own = mode.endswith("-owngemm")                 # the bench's composition: own GEMM on every supported shape + the flat engine (tests/parity.py)
+    autocast = mode.split("-")[0] == "bf16"
     ref = parity.oracle_step(state, x, masks, N, heads, 8)
     anchor = parity.oracle_step(state, x, masks, N, heads, 8, bf16=True) if autocast else None
     model.to(DEV).train()
-    got = parity.native_step_flat(model, {k: v.to(DEV) for k, v in x.items()}, {k: v.to(DEV) for k, v in masks.items()}, N, autocast)
+    xd, md = {k: v.to(DEV) for k, v in x.items()}, {k: v.to(DEV) for k, v in masks.items()}
+    if own:
+        with parity.own_gemm_engaged():
+            got = parity.native_step_flat(model, xd, md, N, autocast, engine=True)
+    else:
+        got = parity.native_step_flat(model, xd, md, N, autocast)
     parity.compare(got, ref, anchor, tol=1e-2 if autocast else 1e-3)
 
 
@@ -56,7 +62,7 @@ def test_c1_tiny_preset_64px_two_live_modalities(mode):
     _full_step(_model("tiny", 64, 31), 3, 2, 64, {"s1": 9, "s2": 7, "dem": 0}, mode)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-owngemm"])
 def test_c2_small_128px_two_live_modalities(mode):
     _full_step(_model("small", 128, 32), 8, 8, 128, {"s1": 37, "s2": 27, "dem": 0}, mode)
 
@@ -101,7 +107,8 @@ def test_c3_vitb_per_sample_modality_dropout_vs_oracle():
             close(r[b:b + 1], want, 1e-3, "ret %d" % b)
 
 
-def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle():
+@pytest.mark.parametrize("own", [False, True], ids=["library", "owngemm"])
+def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle(own):
     """BASELINE config 3 at full width, bf16, INCLUDING the backward: ViT-B, 256 x 256, the model's own per-sample draw with
     uniform task pre-sampling (some samples lose a modality), B = 4.  Every output, loss and parameter gradient of the native
     batch against the per-sample assembly of the oracle (tests/parity.per_sample_oracle), anchored on the oracle's own bf16 run."""
@@ -122,7 +129,11 @@ def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle():
             break
     assert (per_mod == 0).any(), per_mod.tolist()
     masks = {d: tm[d].cpu() for d in O.DOMAINS}
-    got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True)
+    if own:                                                        # the bench's composition (tests/parity.own_gemm_engaged)
+        with parity.own_gemm_engaged():
+            got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True, engine=True)
+    else:
+        got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True)
     ref = parity.per_sample_oracle(state, x, masks, N, 8, 8)
     anchor = parity.per_sample_oracle(state, x, masks, N, 8, 8, bf16=True)
     parity.compare(got, ref, anchor, tol=1e-2)

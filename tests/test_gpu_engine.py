@@ -335,3 +335,58 @@ def test_loss_balancer_companion_follows_the_engine(tmp_path):
     opt_t = create_optimizer(model_t, bal_t, lr=9.0, balancer_lr_scale=scale)
     assert C.auto_load_model(str(tmp_path), model_t, opt_t, loss_balancer=bal_t, map_location="cuda") == 2
     assert opt_t.param_groups[1]["lr"] == pytest.approx(lr * scale) and opt_t.param_groups[1]["lr_scale"] == scale
+
+
+
+def test_failed_backward_does_not_poison_the_next_step():
+    """the deferred split-K sums of weight gradients used to depend on a sticky 'callback registered' flag that only the
+    end-of-backward callback cleared.  A backward() that raises after the first deferral skips autograd's final callbacks: the flag
+    stayed set, later passes never flushed the sums queued after the last per-layer flush (gradients never published, weights
+    silently frozen), and the failed pass's stale partial products were summed into the next pass's buffer.  Now: a step after a
+    failed backward gives exactly the gradients of a step that never saw the failure, and every engine parameter is published."""
+    from incomplete_multimodal_fusion_amd import ops
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep, get_model
+    torch.manual_seed(2)
+    base = get_model("small", input_size=128, decoder_dim=64, decoder_depth=1, decoder_num_heads=2)
+    base.depth = 2; base.blocks = base.blocks[:2]; base.fus_blocks = base.fus_blocks[:2]
+    B, P, N = 64, 64, 96                                  # 10 240 rows: the weight gradients split (S > 1) and are deferred
+    x = {"s1": torch.randn(B, 1, 128, 128, device=DEV), "s2": torch.randn(B, 3, 128, 128, device=DEV),
+         "dem": torch.randn(B, 1, 128, 128, device=DEV)}
+    masks = {}
+    for d, k in (("s1", 40), ("s2", 30), ("dem", 26)):
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1).to(DEV)
+
+    def make():
+        model = copy.deepcopy(base).to(DEV).train()
+        opt = FlatAdamW(model.parameters(), lr=0.0, betas=(0.9, 0.95), weight_decay=0.0, exclude=model.never_used_parameters())
+        return model, opt, PretrainStep(model, opt, N, autocast=True, check_finite=False)
+    model_a, opt_a, step_a = make()
+    model_b, opt_b, step_b = make()
+    step_a(x, task_masks=masks)
+    clean = opt_a.grads.clone()
+    assert all(p.grad is not None for p in opt_a.params)
+    # model b: the first backward dies inside the second per-layer flush, i.e. after deferrals were queued and one flush ran
+    real, n = ops.flush_splitk, [0]
+    deferred = [0]
+    real_append = ops._SPLITK_Q.append
+
+    def dying_flush():
+        n[0] += 1
+        if n[0] == 2:
+            deferred[0] = len(ops._SPLITK_Q)
+            raise RuntimeError("injected failure inside backward")
+        return real()
+    ops.flush_splitk = dying_flush
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            step_b(x, task_masks=masks)
+    finally:
+        ops.flush_splitk = real
+    assert deferred[0] > 0, "the scenario needs deferred split-K sums in flight when backward fails"
+    torch.cuda.synchronize()
+    step_b(x, task_masks=masks)                          # lr = 0: the weights are those of model a
+    assert all(p.grad is not None for p in opt_b.params), [i for i, p in enumerate(opt_b.params) if p.grad is None][:5]
+    assert not ops._SPLITK_Q
+    assert torch.equal(opt_b.grads, clean)

@@ -31,12 +31,17 @@ def _vitb(seed):
     return model
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-owngemm"])
 def test_vitb_full_step_vs_oracle(mode):
     """Every output, loss and parameter gradient of one ViT-B step.  fp32: 1e-3 (gradients 2e-3).  bf16: 1e-2, or -- where a
     tensor exceeds it -- within 1.5x the error the REFERENCE arithmetic itself shows in bf16 on the same weights and inputs
-    (the oracle under CPU bf16 autocast; tests/parity.py).  No hand-picked relaxation."""
+    (the oracle under CPU bf16 autocast; tests/parity.py).  No hand-picked relaxation.
+    bf16-owngemm: the composition the bench runs -- every supported projection on the own GEMM (gemm8p_kernel<0/1>: forward, input
+    gradients through the engine's transposed bf16 shadows, FF1 + GEGLU epilogue with h consumed by geglu_bwd), the step through
+    engine.FlatAdamW with gradients read from its flat buffer; the context asserts the kernels were launched."""
     from tests import parity
+    own = mode.endswith("-owngemm")
+    mode = mode.split("-")[0]
     model = _vitb(21)
     B, P, N = 2, 256, 384
     x = {d: torch.randn(B, c, 256, 256) for d, c in CHANNELS}
@@ -51,8 +56,36 @@ def test_vitb_full_step_vs_oracle(mode):
     anchor = parity.oracle_step(state, x, masks, N, VITB["heads"], VITB["decoder_heads"], bf16=True) if autocast else None
     model.to(DEV).train()
     xd = {k: v.to(DEV) for k, v in x.items()}; md = {k: v.to(DEV) for k, v in masks.items()}
-    got = parity.native_step_flat(model, xd, md, N, autocast)
+    if own:
+        with parity.own_gemm_engaged():
+            got = parity.native_step_flat(model, xd, md, N, autocast, engine=True)
+    else:
+        got = parity.native_step_flat(model, xd, md, N, autocast)
     parity.compare(got, ref, anchor, tol=1e-2 if autocast else 1e-3)
+
+
+def test_vitb_batch64_bf16_step_at_product_dispatch_vs_oracle():
+    """B = 64, bf16, per-sample Dirichlet masks drawn by the product, the step through engine.FlatAdamW at the PRODUCT's own-GEMM
+    threshold (ops._OWN_GEMM_MIN_TILES untouched: at 40 960 rows the K/V, FF1 + GEGLU and FF1 / FF2 input-gradient projections are on
+    gemm8p_kernel, the narrower ones on the library): every output, loss and parameter gradient against the oracle run sample by
+    sample (tests/parity.per_sample_oracle), anchored on the oracle's own bf16 arithmetic."""
+    from tests import parity
+    model = _vitb(23)
+    B, P, N = 64, 256, 384
+    x = {d: torch.randn(B, c, 256, 256) for d, c in CHANNELS}
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    model.per_sample_masks = True
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    torch.manual_seed(7)
+    with torch.no_grad():
+        tm = model(xd, num_encoded_tokens=N, alphas=1.0)[1]
+    masks = {d: tm[d].cpu() for d in O.DOMAINS}
+    with parity.own_gemm_engaged(min_tiles=None):
+        got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True, engine=True)
+    ref = parity.per_sample_oracle(state, x, masks, N, VITB["heads"], VITB["decoder_heads"])
+    anchor = parity.per_sample_oracle(state, x, masks, N, VITB["heads"], VITB["decoder_heads"], bf16=True)
+    parity.compare(got, ref, anchor, tol=1e-2)
 
 
 def test_vitb_batch64_samples_are_independent_and_match_oracle():

@@ -94,3 +94,70 @@ def test_capture_refuses_what_it_cannot_hold():
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     with pytest.raises(NotImplementedError):
         PretrainStep(model, opt, 96).capture(x, masks)
+
+
+def test_resume_into_a_captured_step_replays_like_eager():
+    """capture -> load a checkpoint (model + optimizer state in the reference layout) -> replay: the replays must continue from the
+    RESTORED step counts, learning rate and weight decay, bitwise like the eager run the checkpoint came from (the load
+    used to wipe the replay counter and the lr/wd hand-over flag of the optimizer's control block)."""
+    from incomplete_multimodal_fusion_amd import checkpoint
+    base, x, masks = _setup(7)
+    model_e, opt_e, step_e = _step(base, 0.5)
+    model_g, opt_g, step_g = _step(base, 0.5)
+    sched = [(1e-3, 0.05), (9e-4, 0.05), (7e-4, 0.04), (6e-4, 0.03), (4e-4, 0.02), (2e-4, 0.01)]
+
+    def hyper(opt, i):
+        opt.param_groups[0]["lr"], opt.param_groups[0]["weight_decay"] = sched[i]
+    for i in range(4):
+        hyper(opt_e, i)
+        step_e(x, task_masks=masks)
+    snap_model = {k: v.detach().clone() for k, v in model_e.state_dict().items()}
+    snap_opt = checkpoint.optimizer_state_dict(opt_e, model_e)
+    tail = []
+    for i in (4, 5):
+        hyper(opt_e, i)
+        tail.append(step_e(x, task_masks=masks)["loss"].clone())
+    # the captured step has seen a DIFFERENT history (two warm-up steps + one replay at other hyper-parameters)
+    hyper(opt_g, 5)
+    step_g.capture(x, masks, warmup=2)
+    step_g.replay()
+    model_g.load_state_dict(snap_model, strict=True)
+    checkpoint.load_optimizer_state_dict(opt_g, model_g, snap_opt)
+    assert opt_g.steps == 4
+    for n, i in enumerate((4, 5)):
+        hyper(opt_g, i)
+        out = step_g.replay()
+        assert torch.equal(out["loss"], tail[n]), (i, float(out["loss"]), float(tail[n]))
+    assert opt_g.steps == opt_e.steps == 6
+    assert torch.equal(opt_g.master, opt_e.master) and torch.equal(opt_g.exp_avg, opt_e.exp_avg)
+    assert torch.equal(opt_g.exp_avg_sq, opt_e.exp_avg_sq) and torch.equal(opt_g.shadow, opt_e.shadow)
+
+
+def test_failed_capture_leaves_the_step_eager_and_unchanged():
+    """A capture that raises inside the captured region must leave the step as it was: fresh mask draws per call (not the one
+    static share), the optimizer's step counts untouched by the step that never ran, eager calls still allowed."""
+    base, x, _ = _setup(9)
+    model, opt, step = _step(base)
+    step(x)
+    steps_before = opt.steps
+    orig = step._optimizer_step
+    calls = [0]
+
+    def failing_step():
+        calls[0] += 1
+        if calls[0] == 2:                              # call 1: the eager warm-up step; call 2: inside the capture, before opt.step()
+            raise RuntimeError("injected failure inside the captured region")
+        return orig()
+    step._optimizer_step = failing_step
+    with pytest.raises(RuntimeError, match="injected failure"):
+        step.capture(x, None, warmup=1)
+    step._optimizer_step = orig
+    torch.cuda.synchronize()
+    assert getattr(step, "_graph", None) is None and model.mask_draws is None and step._draws is None
+    assert opt.steps == steps_before + 1               # the ONE warm-up step ran eagerly; the failed captured step advanced nothing
+    assert all(v == opt.steps for v in opt._pstep.values())
+    a = float(step(x)["loss"]); b = float(step(x)["loss"])
+    assert a == a and b == b and a != b                # still training, still drawing fresh masks
+    step.capture(x, None)
+    with pytest.raises(RuntimeError, match="already captured"):
+        step.capture(x, None)
