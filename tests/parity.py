@@ -125,6 +125,43 @@ def per_sample_oracle(state, x, masks, N, heads, dec_heads, bf16=False, domains=
     return {k: v.detach().double().cpu() for k, v in flat.items()}
 
 
+def chunked_oracle(state, x, masks, N, heads, dec_heads, chunk=8, bf16=False, domains=O.DOMAINS):
+    """The oracle's step on a LARGE batch with batch-shared masks, evaluated `chunk` samples at a time (the batched oracle keeps
+    every (B, h, S, S) score matrix for its backward: ~0.9 GB per layer at B = 64).  Exact, not an approximation: every loss term of
+    the step is a mean over samples -- the masked task losses are per-sample ratios averaged over the batch (criterion.py:107-111; no
+    row of a shared mask with live modalities is empty), the DINO term a mean over rows (criterion.py:330-334) -- so the batch loss
+    is the sample-weighted mean of the chunk losses and the gradient the same mean of the chunk gradients."""
+    B = x[domains[0]].shape[0]
+    assert all(int(masks[d][0].sum()) > 0 for d in domains), "chunking needs every modality to have masked patches (no empty mask row)"
+    p = leaf_params(state)
+    outs, task_sum, contra_sum, total = [], {d: 0.0 for d in domains}, 0.0, 0.0
+    for a in range(0, B, chunk):
+        xb = {k: v[a:a + chunk] for k, v in x.items()}
+        mb = {k: v[a:a + chunk] for k, v in masks.items()}
+        w = xb[domains[0]].shape[0] / B
+        out, (tl, lc, l) = O.train_step_loss(p, xb, mb, N, heads, dec_heads, 16, domains=domains, bf16=bf16)
+        (l * w).backward()                                        # gradients accumulate over the chunks
+        for d in domains:
+            task_sum[d] += w * float(tl[d])
+        contra_sum += w * float(lc)
+        total += w * float(l)
+        outs.append(tuple({k: v.detach() for k, v in o.items()} if isinstance(o, dict) else
+                          (o.detach() if torch.is_tensor(o) else o) for o in out))
+    flat = {}
+    for d in domains:
+        flat["pred/" + d] = torch.cat([o[0][d] for o in outs])
+        flat["loss/" + d] = torch.tensor(task_sum[d])
+    flat["pooled"] = torch.cat([o[2] for o in outs]); flat["ori_tokens"] = torch.cat([o[3] for o in outs])
+    flat["fusion_tokens"] = torch.cat([o[4] for o in outs])
+    for i, d in enumerate(domains):
+        flat["ret/" + d] = torch.cat([o[5 + i] for o in outs])
+    flat["loss_contra"], flat["loss"] = torch.tensor(contra_sum), torch.tensor(total)
+    for n, t in p.items():
+        if t.requires_grad and t.grad is not None:
+            flat["grad/" + n] = t.grad
+    return {k: v.detach().double().cpu() for k, v in flat.items()}
+
+
 class own_gemm_engaged:
     """`with parity.own_gemm_engaged(): ...` -- the composition bench.py runs, at test sizes: every projection whose SHAPE the own
     GEMM supports goes to it (ops._OWN_GEMM_MIN_TILES = 0; the product threshold of 512 tiles keeps B <= 8 steps on the library GEMM),
