@@ -285,7 +285,7 @@ def compare(got: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], anchor: 
                 bad.append("%s: gradient where the reference has none" % name)
     summary = ""
     rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" (")[0], "mode": "fp32" if anchor is None else "bf16-anchored",
-           "tol": tol, "tensors": len(rows), "failed": len(bad)}
+           "tol": tol, "pred_l2_tol": pred_l2_tol, "tensors": len(rows), "failed": len(bad)}
     outs_ = [r for r in rows if not r[0].startswith("grad/")]
     grads_ = [r for r in rows if r[0].startswith("grad/")]
     rec["outputs"] = len(outs_); rec["outputs_above_tol"] = sum(1 for r in outs_ if r[1] > tol)

@@ -28,6 +28,14 @@ def main(path):
             f(r.get("grad_rel_l2_hip")), f(r.get("grad_rel_l2_anchor")),
             ("%.2f (`%s`)" % (r["worst_ratio"], r.get("worst_tensor", ""))) if "worst_ratio" in r else "-",
             f(r.get("median_ratio"), "%.2f"), r["failed"]))
+    exc = [r for r in rows if r.get("pred_l2_tol") is not None and r["pred_l2_tol"] > r["tol"] * (1 + 1e-9)]
+    if exc:
+        print("\nEXCEPTIONS to the strict prediction clause (a test that raises `pred_l2_tol` above the plain tolerance is listed here with "
+              "the reference arithmetic's own figure, the anchor):\n")
+        for r in exc:
+            print("* `%s`: prediction images held to rel L2 %.0e instead of %.0e -- measured %s, the oracle's own bf16 run (anchor) %s: the "
+                  "reference's arithmetic in bf16 does not meet the plain figure on this fixture either."
+                  % (r.get("test", "").replace("tests/", ""), r["pred_l2_tol"], r["tol"], f(r.get("pred_rel_l2_max")), f(r.get("pred_rel_l2_max_anchor"))))
     bad = sum(1 for r in rows if r["failed"])
     bf = [r for r in rows if r["mode"] != "fp32"]
     print("\n%d compare() calls, %d with a failing tensor; strict clause worst cases over the bf16 runs: loss scalar %s, prediction rel L2 %s "
