@@ -215,6 +215,13 @@ int mmae_shadow_bf16(long n, const float* p, void* shadow_bf16, void* stream);
  * {int64 src element offset of the tile, int64 dst element offset, int32 ld_src, int32 ld_dst, int32 rows, int32 cols}
  * with rows, cols <= 64 and multiples of 8, all offsets multiples of 8 elements. */
 int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16, const void* tiles, int n_tiles, void* stream);
+/* Zero-padded (optionally transposed) bf16 copies of weight blocks in ONE launch: the own GEMM needs K % 128 == 0 and N % 256 == 0, and
+ * ViT-L's GEGLU width ffi = int(1024 * 8 / 3) = 2730 (pretraining/multimae/multimae_crossattn.py:584-599 building
+ * downstream/.../multimae/zorro_utils.py:121-128 FeedForward) fits neither; the optimizer engine keeps FeedForward[1] / [3] weights padded
+ * to 2816 (pads zero: inert) beside the flat bf16 shadow.  One tile of <= 64 x 64 SOURCE elements per row of `tiles`, 48 bytes each:
+ * {uint64 src address, uint64 dst address, int32 ld_src, int32 ld_dst (elements), int32 rows, int32 cols (any value <= 64),
+ *  int32 transpose, 12 bytes reserved}.  dst[r][c] (or dst[c][r]) = src[r][c] for r < rows, c < cols; nothing else is written. */
+int mmae_pad_copy_bf16_batched(const void* tiles, int n_tiles, void* stream);
 /* out[i] = sum_s partials[s*n + i], fp32 accumulation in fixed order: reduction of the S bf16 partial products of a split-K
  * weight-gradient GEMM (autograd of nn.Linear in the reference) into its fp32 destination.  n % 8 == 0. */
 int mmae_splitk_sum(int S, long n, const void* partials_bf16, float* out, void* stream);

@@ -105,6 +105,57 @@ __global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const bf16*
     }
 }
 
+// Zero-PADDED (and optionally transposed) bf16 copies of weight blocks whose sizes do not fit the own GEMM's tiles -- ViT-L's GEGLU width
+// ffi = int(1024 * 8 / 3) = 2730 (reference: MM/multimae_crossattn.py:584-599 -> DSI-MM/zorro_utils.py:121-128) is no multiple of the
+// 64-deep K-tile nor of the 256-wide N-tile: the engine keeps copies padded to 2816 (pads are zero, i.e. mathematically inert) and refreshes
+// them after every update with ONE launch.  One tile of up to 64 x 64 source elements per table row (48 bytes):
+//   {src address, dst address (bytes, absolute), ld_src, ld_dst (elements), rows, cols (<= 64, ANY value), transpose (0 / 1)}
+// dst[r][c] = src[r][c] (transpose 0) or dst[c][r] = src[r][c] (transpose 1) for r < rows, c < cols; nothing else is written, so the pad
+// region of a destination that was zero-filled once stays zero.  Edges are element-granular (2730 % 8 = 2); full, 16-byte aligned chunks
+// move as vectors.
+struct PadTile { unsigned long long src, dst; int ld_src, ld_dst, nr, nc, tr, pad_; long long pad2_; };
+static_assert(sizeof(PadTile) == 48, "PadTile layout is part of the C ABI (mmae_pad_copy_bf16_batched)");
+
+__global__ __launch_bounds__(256) void pad_copy_bf16_batched_kernel(const PadTile* __restrict__ tiles) {
+    __shared__ bf16 lds[64][72];
+    const PadTile t = tiles[blockIdx.x];
+    const bf16* src = reinterpret_cast<const bf16*>(t.src);
+    bf16* dst = reinterpret_cast<bf16*>(t.dst);
+    const int v = (threadIdx.x & 7) * 8, r = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = r + 32 * pass;
+        if (row < t.nr && v < t.nc) {
+            const bf16* sp = src + (long)row * t.ld_src + v;
+            if (v + 8 <= t.nc && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+                *reinterpret_cast<uint4*>(&lds[row][v]) = *reinterpret_cast<const uint4*>(sp);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lds[row][v + i] = (v + i < t.nc) ? sp[i] : (bf16)0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int n_along = t.tr ? t.nr : t.nc, n_across = t.tr ? t.nc : t.nr;       // destination: `across` rows of `along` elements
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int drow = r + 32 * pass;
+        if (drow < n_across && v < n_along) {
+            union { uint4 q; bf16 e[8]; } o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = t.tr ? lds[(v + i) & 63][drow] : lds[drow][(v + i) & 63];
+            bf16* dp = dst + (long)drow * t.ld_dst + v;
+            if (v + 8 <= n_along && (reinterpret_cast<uintptr_t>(dp) & 15) == 0) {
+                *reinterpret_cast<uint4*>(dp) = o.q;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v + i < n_along) dp[i] = o.e[i];
+            }
+        }
+    }
+}
+
 // out[i] = sum_s part[s*n + i]: fp32 reduction of the S bf16 partial products of a split-K weight-gradient GEMM, written
 // straight to its fp32 destination (the flat gradient buffer).  8 elements per lane, fixed summation order.
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const bf16* __restrict__ part, int S, long n, float* __restrict__ out) {
@@ -243,6 +294,15 @@ extern "C" int mmae_transpose_bf16_batched(const void* src_bf16, void* dst_bf16,
     MMAE_LAUNCH(transpose_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16*>(src_bf16), reinterpret_cast<bf16*>(dst_bf16),
                        reinterpret_cast<const TrTile*>(tiles));
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+extern "C" int mmae_pad_copy_bf16_batched(const void* tiles, int n_tiles, void* stream) {
+    if (n_tiles < 0 || !tiles) return MMAE_ERR_ARG;
+    if (n_tiles == 0) return MMAE_OK;
+    MMAE_LAUNCH(pad_copy_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const PadTile*>(tiles));
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

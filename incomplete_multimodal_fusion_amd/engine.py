@@ -75,6 +75,9 @@ class FlatAdamW:
         self.shadow_t: Optional[torch.Tensor] = None
         self._tr: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._tr_tiles: Optional[torch.Tensor] = None
+        # zero-padded copies of FeedForward weights whose width does not fit the own GEMM's tiles (padded_ff): refreshed with the shadows
+        self._pad: Dict[Tuple[int, int], "PaddedFF"] = {}
+        self._pad_tiles: Optional[torch.Tensor] = None
         self.refresh_shadow()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.param_groups = [{"params": self.params, "lr": lr, "weight_decay": weight_decay, "lr_scale": 1.0}]
@@ -125,7 +128,36 @@ class FlatAdamW:
     # -- update ------------------------------------------------------------------------------------------------------
     def refresh_shadow(self):
         call("mmae_shadow_bf16", self.n, ptr(self.master), ptr(self.shadow), stream())
-        self._refresh_transposed()
+        self._refresh_derived()
+
+    def padded_ff(self, w1: torch.nn.Parameter, w2: torch.nn.Parameter) -> Optional["PaddedFF"]:
+        """bf16 copies of a FeedForward's weights W1 (2F, D) / W2 (D, F) with the GEGLU width F zero-padded to Fp = the next multiple of
+        256, plus their transposes -- the operand layouts csrc/gemm.hip needs when F fits none of its tiles (ViT-L: F = 2730 -> 2816):
+            w1p (2 Fp, D): val rows [0, F), gate rows [Fp, Fp + F)      w1pt (D, 2 Fp) = w1p^T
+            w2p (D, Fp)                                                  w2pt (Fp, D)  = w2p^T
+        Pads are zero and never written (mathematically inert: h, g, dg, dh are zero in the pad columns).  Registered on first use,
+        refreshed after every update by ONE launch (mmae_pad_copy_bf16_batched).  None if the weights are not both held by this engine."""
+        if id(w1) not in self.offsets or id(w2) not in self.offsets or w1.dim() != 2 or w2.dim() != 2:
+            return None
+        key = (self.offsets[id(w1)], self.offsets[id(w2)])
+        pf = self._pad.get(key)
+        if pf is not None:
+            return pf
+        D, F = w2.shape
+        if w1.shape != (2 * F, D):
+            return None
+        pf = PaddedFF(self, key[0], key[1], D, F)
+        self._pad[key] = pf
+        self._pad_tiles = None
+        call("mmae_pad_copy_bf16_batched", ptr(pf.tiles), pf.tiles.shape[0], stream())      # first fill (later: with all the others)
+        return pf
+
+    def _refresh_padded(self):
+        if not self._pad:
+            return
+        if self._pad_tiles is None:
+            self._pad_tiles = torch.cat([pf.tiles for pf in self._pad.values()], 0).contiguous()
+        call("mmae_pad_copy_bf16_batched", ptr(self._pad_tiles), self._pad_tiles.shape[0], stream())
 
     def transposed_shadow(self, o0: int, R: int, C: int) -> Optional[torch.Tensor]:
         """(C, R) bf16 view holding the transpose of the (R, C) weight block at flat offset o0; None if the block cannot
@@ -165,6 +197,11 @@ class FlatAdamW:
             self._tr_tiles = torch.from_numpy(tab.view(np.uint8).reshape(-1, 32).copy()).to(self.master.device)
         call("mmae_transpose_bf16_batched", ptr(self.shadow), ptr(self.shadow_t), ptr(self._tr_tiles),
              self._tr_tiles.shape[0], stream())
+
+    def _refresh_derived(self):
+        """Everything derived from the bf16 shadow, after an update: transposed shadows, padded FeedForward copies."""
+        self._refresh_transposed()
+        self._refresh_padded()
 
     def _update_ranges(self):
         """[(flat offset, length, step count)] of the runs of parameters that hold a gradient (torch.optim.AdamW skips
@@ -237,7 +274,7 @@ class FlatAdamW:
                 # out must not lose a step for it.  Host sync, only when the set of used parameters varies (downstream).
                 for p in absent:
                     self._pstep[id(p)] += 1
-        self._refresh_transposed()
+        self._refresh_derived()
 
     # -- hipGraph capture of the step (pretrain.PretrainStep.capture) ---------------------------------------------------
     def begin_capture(self):
@@ -333,6 +370,63 @@ class FlatAdamW:
             self._pstep[id(p)] = int(steps.get(id(p), 0))
         self.steps = max(self._pstep.values()) if self._pstep else 0
         self._counts_restored()
+
+
+class PaddedFF:
+    """Zero-padded bf16 operand copies of one FeedForward (FlatAdamW.padded_ff) and the tile table that refreshes them."""
+
+    def __init__(self, eng: "FlatAdamW", o1: int, o2: int, D: int, F: int):
+        import numpy as np
+        dev = eng.master.device
+        Fp = (F + 255) // 256 * 256
+        self.F, self.Fp, self.D = F, Fp, D
+        self.w1p = torch.zeros(2 * Fp, D, dtype=torch.bfloat16, device=dev)
+        self.w2p = torch.zeros(D, Fp, dtype=torch.bfloat16, device=dev)
+        self.w1pt = torch.zeros(D, 2 * Fp, dtype=torch.bfloat16, device=dev)
+        self.w2pt = torch.zeros(Fp, D, dtype=torch.bfloat16, device=dev)
+        s1 = eng.shadow.data_ptr() + 2 * o1          # W1 (2F, D) row-major
+        s2 = eng.shadow.data_ptr() + 2 * o2          # W2 (D, F)  row-major
+        rows = []
+
+        def grid(nr_all, nc_all):
+            r = np.arange(0, nr_all, 64)[:, None].repeat((nc_all + 63) // 64, 1).reshape(-1)
+            c = np.tile(np.arange(0, nc_all, 64), (nr_all + 63) // 64)
+            return r, c, np.minimum(64, nr_all - r), np.minimum(64, nc_all - c)
+
+        def add(src, dst, ld_src, ld_dst, nr, nc, tr):
+            t = np.zeros(len(nr), dtype=_PAD_TILE)
+            t["src"], t["dst"], t["ld_src"], t["ld_dst"], t["nr"], t["nc"], t["tr"] = src, dst, ld_src, ld_dst, nr, nc, tr
+            rows.append(t)
+        r, c, nr, nc = grid(F, D)
+        for r_src0, r_dst0 in ((0, 0), (F, Fp)):                  # val block, gate block of W1
+            src = s1 + 2 * ((r_src0 + r) * D + c)
+            add(src, self.w1p.data_ptr() + 2 * ((r_dst0 + r) * D + c), D, D, nr, nc, 0)
+            add(src, self.w1pt.data_ptr() + 2 * (c * (2 * Fp) + r_dst0 + r), D, 2 * Fp, nr, nc, 1)
+        r, c, nr, nc = grid(D, F)
+        src = s2 + 2 * (r * F + c)
+        add(src, self.w2p.data_ptr() + 2 * (r * Fp + c), F, Fp, nr, nc, 0)
+        add(src, self.w2pt.data_ptr() + 2 * (c * D + r), F, D, nr, nc, 1)
+        tab = np.concatenate(rows)
+        self.tiles = torch.from_numpy(tab.view(np.uint8).reshape(-1, 48).copy()).to(dev)
+
+
+try:
+    import numpy as _np
+    _PAD_TILE = _np.dtype([("src", "<u8"), ("dst", "<u8"), ("ld_src", "<i4"), ("ld_dst", "<i4"), ("nr", "<i4"), ("nc", "<i4"),
+                           ("tr", "<i4"), ("pad_", "<i4"), ("pad2_", "<i8")])
+    assert _PAD_TILE.itemsize == 48
+except ImportError:                                   # numpy is a hard dependency of torch anyway
+    _PAD_TILE = None
+
+
+def padded_ff_of(w1, w2, dtype) -> Optional[PaddedFF]:
+    """The engine's zero-padded operand copies of FeedForward weights (w1 (2F, D), w2 (D, F)), or None (no engine / not bf16)."""
+    if dtype != torch.bfloat16 or not hasattr(w1, "_mmae_flat") or not hasattr(w2, "_mmae_flat"):
+        return None
+    eng = w1._mmae_flat[0]
+    if w2._mmae_flat[0] is not eng:
+        return None
+    return eng.padded_ff(w1, w2)
 
 
 def shadow_of(ws, dtype) -> Optional[torch.Tensor]:

@@ -468,10 +468,12 @@ def _end_of_backward_flush():
     flush_splitk()
 
 
-def _wgrad(g2, x2, gview, publish=None):
+def _wgrad(g2, x2, gview, publish=None, defer=False):
     """dW = g2^T x2 in fp32, written into `gview` when given: the own transposing split-K kernel where it applies, else a split-K
     batched library GEMM + sum.  publish: the weights whose in-place gradient this is -- the call then publishes it itself
-    (engine.grads_written_in_place), at once or, for a deferred split-K sum, at the flush; the caller must not."""
+    (engine.grads_written_in_place), at once or, for a deferred split-K sum, at the flush; the caller must not.
+    defer (with gview, no publish): the split-K sum may join the deferred queue although THIS call publishes nothing -- a later call
+    of the same backward node publishes the weights (one gradient assembled from several GEMMs); the caller guarantees that call."""
     rows, n_out, n_in = g2.shape[0], g2.shape[1], x2.shape[1]
 
     def done(out):
@@ -486,7 +488,7 @@ def _wgrad(g2, x2, gview, publish=None):
         part = torch.bmm(g2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in))
         if part.dtype == torch.bfloat16 and (n_out * n_in) % 8 == 0:
             out = gview if gview is not None else torch.empty(n_out, n_in, dtype=torch.float32, device=g2.device)
-            if publish is not None and gview is not None and DEFER_SPLITK and _lib.raw_stream() == 0:      # the default stream
+            if (publish is not None or defer) and gview is not None and DEFER_SPLITK and _lib.raw_stream() == 0:      # the default stream
                 if not _SPLITK_Q:       # empty -> non-empty: this backward pass flushes at its end (a few per pass: _KvQ flushes per layer)
                     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_flush)
                 _SPLITK_Q.append((part, S, n_out * n_in, out, publish))
@@ -1085,6 +1087,7 @@ def drop_path_row_scale(u: torch.Tensor, drop_prob: float, counts):
     return torch.cat([s.repeat_interleave(int(c)) for c in counts]).contiguous()
 
 FF_CHUNKS = 1      # see _FeedForwardGEGLU: 2 was measured, no net gain
+PAD_FF = True      # a GEGLU width that fits none of the own GEMM's tiles (ViT-L: 2730) runs on zero-padded operand copies (tools/tuning_env.py: MMAE_PAD_FF)
 
 
 def _row_chunks(rows: int, n: int):
@@ -1108,16 +1111,42 @@ class _FeedForwardGEGLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, w1, w2):
-        from .engine import grad_view_of, shadow_of
+        from .engine import grad_view_of, padded_ff_of, shadow_of
         T = y.dtype
         y = _c(y)
+        rows, F = y.shape[0], w2.shape[1]
+        assert w1.shape[0] == 2 * F and y.dim() == 2
+        f32 = w1.dtype == torch.float32 and w2.dtype == torch.float32
+        gv1, gv2 = (grad_view_of((w1,)), grad_view_of((w2,))) if f32 else (None, None)
+        # A GEGLU width that fits none of the own GEMM's tiles (ViT-L: int(1024 * 8 / 3) = 2730) runs on the engine's zero-PADDED
+        # operand copies (width Fp = 2816; pads are zero, so h, g, dg, dh are zero there and every product is unchanged) when the
+        # projections are big enough for the own kernel at all; otherwise on the library GEMMs at the exact width.
+        pf = None
+        if PAD_FF and F % 256 and T == torch.bfloat16 and (OWN_GEMM & 1) and gv1 is not None and gv2 is not None:
+            Fp = (F + 255) // 256 * 256
+            D = w2.shape[0]
+            lib_ = _lib.lib()
+            if ((rows + 255) // 256) * (D // 256) >= _OWN_GEMM_MIN_TILES and y.data_ptr() % 16 == 0 and \
+                    lib_.mmae_gemm_geglu_supported(rows, Fp, D, y.stride(0), D, 2 * Fp, Fp) and \
+                    lib_.mmae_gemm_nt_supported(rows, D, Fp, Fp, Fp, D) and lib_.mmae_gemm_nt_supported(rows, Fp, D, D, D, Fp) and \
+                    lib_.mmae_gemm_nt_supported(rows, D, 2 * Fp, 2 * Fp, 2 * Fp, D):
+                pf = padded_ff_of(w1, w2, T)
+        if pf is not None:
+            Fp = pf.Fp
+            h = torch.empty(rows, 2 * Fp, dtype=T, device=y.device)
+            g = torch.empty(rows, Fp, dtype=T, device=y.device)
+            f = torch.empty(rows, w2.shape[0], dtype=T, device=y.device)
+            with _NoAutocast():
+                gemm_geglu(y, pf.w1p, h, g)                          # h = [val | pad | gate | pad], g = [GEGLU | pad]; pads come out zero
+                gemm_nt(g, pf.w2p, f)
+            ctx.save_for_backward(y, h, g)
+            ctx.cfg = (w1, w2, gv1, gv2, pf)
+            return f
 
         def cast(w):
             c = shadow_of((w,), T)
             return c if c is not None else (w if w.dtype == T else w.to(T))
         w1c, w2c = cast(w1), cast(w2)
-        rows, F = y.shape[0], w2.shape[1]
-        assert w1.shape[0] == 2 * F and y.dim() == 2
         h = torch.empty(rows, 2 * F, dtype=T, device=y.device)
         g = torch.empty(rows, F, dtype=T, device=y.device)
         f = torch.empty(rows, w2.shape[0], dtype=T, device=y.device)
@@ -1130,16 +1159,30 @@ class _FeedForwardGEGLU(torch.autograd.Function):
                     call("mmae_geglu_fwd", dt(T), b - a, F, ptr(h[a:b]), ptr(g[a:b]), stream())
                 matmul_nt(g[a:b], w2c, out=f[a:b])
         ctx.save_for_backward(y, h, g, w1c, w2c)
-        f32 = w1.dtype == torch.float32 and w2.dtype == torch.float32
-        ctx.cfg = (w1, w2, grad_view_of((w1,)) if f32 else None, grad_view_of((w2,)) if f32 else None)
+        ctx.cfg = (w1, w2, gv1, gv2, None)
         return f
 
     @staticmethod
     def backward(ctx, df):
         from .engine import shadow_t_of
-        y, h, g, w1c, w2c = ctx.saved_tensors
-        w1, w2, gv1, gv2 = ctx.cfg
+        w1, w2, gv1, gv2, pf = ctx.cfg
         df = _c(df)
+        if pf is not None:
+            y, h, g = ctx.saved_tensors
+            T, rows, F, Fp = y.dtype, y.shape[0], pf.F, pf.Fp
+            dh = torch.empty_like(h)
+            dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+            with _NoAutocast():
+                dg = gemm_nt(df, pf.w2pt)                                     # (rows, Fp); zero in the pad columns (zero rows of w2pt)
+                call("mmae_geglu_bwd", dt(T), rows, Fp, ptr(h), ptr(dg), ptr(dh), stream())
+                if dy is not None:
+                    gemm_nt(dh, pf.w1pt, dy)                                  # contraction over 2 Fp: the pad columns of dh are zero
+                # weight gradients at the EXACT width, straight into the flat fp32 buffer: column slices of the padded activations
+                _wgrad(df, g[:, :F], gv2, None, defer=True)
+                _wgrad(dh[:, :F], y, gv1[:F], None, defer=True)               # val rows of W1
+                _wgrad(dh[:, Fp:Fp + F], y, gv1[F:], (w2, w1))                # gate rows; publishes both weights (after all three sums)
+            return dy, None, None
+        y, h, g, w1c, w2c = ctx.saved_tensors
         T = y.dtype
         rows, F = y.shape[0], g.shape[1]
         w1t = shadow_t_of((w1,), T)

@@ -67,7 +67,7 @@ def test_c2_small_128px_two_live_modalities(mode):
     _full_step(_model("small", 128, 32), 8, 8, 128, {"s1": 37, "s2": 27, "dem": 0}, mode)
 
 
-@pytest.mark.parametrize("mode", ["bf16"])
+@pytest.mark.parametrize("mode", ["bf16", "bf16-owngemm"])
 def test_c5_vit_large_depth24_three_modalities(mode):
     _full_step(_model("large", 256, 33), 8, 2, 256, {"s1": 150, "s2": 61, "dem": 173}, mode)
 

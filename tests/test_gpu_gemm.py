@@ -161,3 +161,76 @@ def test_gemm_tn_strided_operands():
     G, X = Gw[:, N:2 * N], Xw[:, :Kin]
     assert _lib.lib().mmae_gemm_tn_supported(rows, N, Kin, G.stride(0), X.stride(0)) and G.data_ptr() % 16 == 0
     close(ops.gemm_tn(G, X), G.double().t() @ X.double(), 1e-3, "strided wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ zero-padded FeedForward (ViT-L's ffi = 2730)
+def _ff_engine(D, F, seed=0):
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    torch.manual_seed(seed)
+    w1 = torch.nn.Parameter(torch.randn(2 * F, D, device=DEV) * D ** -0.5)
+    w2 = torch.nn.Parameter(torch.randn(D, F, device=DEV) * F ** -0.5)
+    return w1, w2, FlatAdamW([w1, w2], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
+
+
+@pytest.mark.parametrize("D,F", [(128, 90), (512, 300), (1024, 2730)])
+def test_padded_ff_shadows_match_the_weights(D, F):
+    """engine.FlatAdamW.padded_ff: the zero-padded / transposed bf16 copies (mmae_pad_copy_bf16_batched, element-granular edges:
+    2730 % 8 = 2) hold exactly the shadow's values in their payload and zeros in the pads -- at registration and after an update."""
+    w1, w2, eng = _ff_engine(D, F)
+    pf = eng.padded_ff(w1, w2)
+    Fp = pf.Fp
+    assert Fp % 256 == 0 and Fp >= F and Fp - F < 256
+
+    def check():
+        s1, s2 = w1._mmae_shadow, w2._mmae_shadow
+        e1 = torch.zeros(2 * Fp, D, dtype=torch.bfloat16, device=DEV); e1[:F] = s1[:F]; e1[Fp:Fp + F] = s1[F:]
+        e2 = torch.zeros(D, Fp, dtype=torch.bfloat16, device=DEV); e2[:, :F] = s2
+        assert torch.equal(pf.w1p, e1) and torch.equal(pf.w2p, e2)
+        assert torch.equal(pf.w1pt, e1.t().contiguous()) and torch.equal(pf.w2pt, e2.t().contiguous())
+    check()
+    w1.grad = torch.randn_like(w1); w2.grad = torch.randn_like(w2)
+    eng._on_grad(w1); eng._on_grad(w2)
+    before = pf.w1p.clone()
+    eng.step()
+    assert not torch.equal(pf.w1p, before)
+    check()
+
+
+@pytest.mark.parametrize("rows,D,F", [(4096, 512, 300), (6000, 1024, 2730)])
+def test_feedforward_geglu_padded_own_gemm_vs_fp64_and_library_path(rows, D, F, monkeypatch):
+    """ops.feedforward_geglu at a GEGLU width that fits none of the own GEMM's tiles: the padded path (gemm8p on the engine's padded
+    copies; asserted engaged) against the fp64 composition of zorro_utils.py:115-128 and against the library path at the exact width --
+    output, input gradient and both weight gradients (written in place into the flat buffer at the EXACT shapes)."""
+    from incomplete_multimodal_fusion_amd import ops
+    w1, w2, eng = _ff_engine(D, F, 1)
+    y = (torch.randn(rows, D, device=DEV) * 0.7).to(torch.bfloat16).requires_grad_(True)
+    df = (torch.randn(rows, D, device=DEV) * 0.5).to(torch.bfloat16)
+
+    def run(min_tiles, own):
+        monkeypatch.setattr(ops, "_OWN_GEMM_MIN_TILES", min_tiles)
+        monkeypatch.setattr(ops, "OWN_GEMM", own)
+        eng.zero_grad(); y.grad = None
+        before = dict(ops.CALLS)
+        f = ops.feedforward_geglu(y, w1, w2)
+        f.backward(df)
+        eng.grad_norm()                                                 # flushes deferred split-K sums
+        calls = {k: ops.CALLS[k] - before[k] for k in before}
+        assert w1.grad is not None and w2.grad is not None
+        return f.detach().float(), y.grad.detach().float(), w1._mmae_grad.clone(), w2._mmae_grad.clone(), calls
+    f_p, dy_p, g1_p, g2_p, calls = run(0, 1)
+    assert calls["mmae_gemm_geglu"] == 1 and calls["mmae_gemm_nt"] == 3, calls
+    f_l, dy_l, g1_l, g2_l, calls_l = run(1 << 30, 0)
+    assert calls_l["mmae_gemm_geglu"] == 0 and calls_l["mmae_gemm_nt"] == 0
+    # fp64 reference on the bf16-rounded operands the GPU paths read
+    yd = y.detach().double().cpu().requires_grad_(True)
+    a1 = w1._mmae_shadow.double().cpu().requires_grad_(True); a2 = w2._mmae_shadow.double().cpu().requires_grad_(True)
+    h = yd @ a1.t()
+    val, gate = h[:, :F], h[:, F:]
+    fr = (val * torch.nn.functional.gelu(gate)) @ a2.t()
+    fr.backward(df.double().cpu())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    for name, got_p, got_l, ref in (("f", f_p, f_l, fr.detach()), ("dy", dy_p, dy_l, yd.grad), ("dW1", g1_p, g1_l, a1.grad), ("dW2", g2_p, g2_l, a2.grad)):
+        ep, el = rel(got_p, ref), rel(got_l, ref)
+        assert ep < 1.2e-2 and ep < 1.5 * el + 1e-3, (name, ep, el)       # bf16 intermediates (h, g, dg, dh): same rounding points in both paths
