@@ -1088,6 +1088,7 @@ def drop_path_row_scale(u: torch.Tensor, drop_prob: float, counts):
 
 FF_CHUNKS = 1      # see _FeedForwardGEGLU: 2 was measured, no net gain
 PAD_FF = True      # a GEGLU width that fits none of the own GEMM's tiles (ViT-L: 2730) runs on zero-padded operand copies (tools/tuning_env.py: MMAE_PAD_FF)
+PAD_FF_MIN_TILES = 512     # ... when FeedForward[3] has at least this many output tiles (the alternative there is a library GEMM at an unaligned width)
 
 
 def _row_chunks(rows: int, n: int):
@@ -1126,7 +1127,7 @@ class _FeedForwardGEGLU(torch.autograd.Function):
             Fp = (F + 255) // 256 * 256
             D = w2.shape[0]
             lib_ = _lib.lib()
-            if ((rows + 255) // 256) * (D // 256) >= _OWN_GEMM_MIN_TILES and y.data_ptr() % 16 == 0 and \
+            if ((rows + 255) // 256) * (D // 256) >= min(_OWN_GEMM_MIN_TILES, PAD_FF_MIN_TILES) and y.data_ptr() % 16 == 0 and \
                     lib_.mmae_gemm_geglu_supported(rows, Fp, D, y.stride(0), D, 2 * Fp, Fp) and \
                     lib_.mmae_gemm_nt_supported(rows, D, Fp, Fp, Fp, D) and lib_.mmae_gemm_nt_supported(rows, Fp, D, D, D, Fp) and \
                     lib_.mmae_gemm_nt_supported(rows, D, 2 * Fp, 2 * Fp, 2 * Fp, D):
