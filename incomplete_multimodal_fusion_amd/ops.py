@@ -1088,7 +1088,8 @@ def drop_path_row_scale(u: torch.Tensor, drop_prob: float, counts):
 
 FF_CHUNKS = 1      # see _FeedForwardGEGLU: 2 was measured, no net gain
 PAD_FF = True      # a GEGLU width that fits none of the own GEMM's tiles (ViT-L: 2730) runs on zero-padded operand copies (tools/tuning_env.py: MMAE_PAD_FF)
-PAD_FF_MIN_TILES = 512     # ... when FeedForward[3] has at least this many output tiles (the alternative there is a library GEMM at an unaligned width)
+PAD_FF_MIN_TILES = 128     # ... when FeedForward[3] has at least this many output tiles.  Lower than _OWN_GEMM_MIN_TILES: the alternative here is a
+                           # library GEMM at an unaligned width (config 5, same-box A/B: 512 -> 128 is 153.2 -> 146.8 ms/step; no padding: 169.0)
 
 
 def _row_chunks(rows: int, n: int):

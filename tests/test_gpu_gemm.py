@@ -125,7 +125,12 @@ def test_gemm_geglu_matches_separate_path(M, F, K):
     close(h, ref_h, 1e-2, "h")
     sep = ops.geglu(h)                                               # the separate kernel on the same h
     assert float((g.float() - sep.float()).abs().max()) <= 2 ** -7 * max(float(sep.float().abs().max()), 1e-6), "g vs geglu(h)"
-    assert float(((g.float() - sep.float()).abs() > 0).float().mean()) < 1e-3     # same formula, same rounding: (almost) bit-identical
+    # the epilogue's GELU form (csrc/gemm.hip gm_gelu) is within 2.6e-5 of the separate kernel's for every bf16 gate
+    # (tools/probes/gelu_form_check.py): element by element the two products differ by that times |val| plus one rounding step
+    d = (g.float() - sep.float()).abs()
+    bound = 2 ** -7 * sep.float().abs() + 3e-5 * h[:, :F].float().abs() + 1e-30
+    assert bool((d <= bound).all()), float((d / bound).max())
+    assert float((d > 0).float().mean()) < 5e-2                      # and most elements are bit-identical
     h64 = ref_h.double()
     close(g, O.gelu_erf(h64[:, F:]) * h64[:, :F], 1e-2, "g vs fp64")
 
