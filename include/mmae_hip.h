@@ -22,10 +22,11 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 5   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
+#define MMAE_ABI_VERSION 6   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
                                 mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
                                 mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn, mmae_splitk_sum_multi.  5: the optimizer control block grew
-                                from 4 to 8 floats (mmae_adamw_control / _step_ctl read [4], [5]); + mmae_adamw_tick, mmae_mha_fwd_route */
+                                from 4 to 8 floats (mmae_adamw_control / _step_ctl read [4], [5]); + mmae_adamw_tick, mmae_mha_fwd_route.  6: + mmae_pad_copy_bf16_batched
+                                (additive: no existing signature changed) */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
