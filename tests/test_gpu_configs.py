@@ -37,7 +37,7 @@ def _masks(P, B, keep):
     return masks
 
 
-def _full_step(model, heads, B, size, keep, mode):
+def _full_step(model, heads, B, size, keep, mode, key=None):
     P = (size // 16) ** 2
     x = {"s1": torch.randn(B, 1, size, size), "s2": torch.randn(B, 3, size, size), "dem": torch.randn(B, 1, size, size)}
     masks = _masks(P, B, keep)
@@ -45,8 +45,7 @@ def _full_step(model, heads, B, size, keep, mode):
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     own = mode.endswith("-owngemm")                 # the bench's composition: own GEMM on every supported shape + the flat engine (tests/parity.py)
     autocast = mode.split("-")[0] == "bf16"
-    ref = parity.oracle_step(state, x, masks, N, heads, 8)
-    anchor = parity.oracle_step(state, x, masks, N, heads, 8, bf16=True) if autocast else None
+    ref, anchor = parity.cached_oracle((key, autocast), state, x, masks, N, heads, 8, anchor=autocast)    # shared by the library / own-GEMM cases
     model.to(DEV).train()
     xd, md = {k: v.to(DEV) for k, v in x.items()}, {k: v.to(DEV) for k, v in masks.items()}
     if own:
@@ -59,17 +58,17 @@ def _full_step(model, heads, B, size, keep, mode):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_c1_tiny_preset_64px_two_live_modalities(mode):
-    _full_step(_model("tiny", 64, 31), 3, 2, 64, {"s1": 9, "s2": 7, "dem": 0}, mode)
+    _full_step(_model("tiny", 64, 31), 3, 2, 64, {"s1": 9, "s2": 7, "dem": 0}, mode, key="c1")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-owngemm"])
 def test_c2_small_128px_two_live_modalities(mode):
-    _full_step(_model("small", 128, 32), 8, 8, 128, {"s1": 37, "s2": 27, "dem": 0}, mode)
+    _full_step(_model("small", 128, 32), 8, 8, 128, {"s1": 37, "s2": 27, "dem": 0}, mode, key="c2")
 
 
 @pytest.mark.parametrize("mode", ["bf16", "bf16-owngemm"])
 def test_c5_vit_large_depth24_three_modalities(mode):
-    _full_step(_model("large", 256, 33), 8, 2, 256, {"s1": 150, "s2": 61, "dem": 173}, mode)
+    _full_step(_model("large", 256, 33), 8, 2, 256, {"s1": 150, "s2": 61, "dem": 173}, mode, key="c5")
 
 
 def test_c3_vitb_per_sample_modality_dropout_vs_oracle():
@@ -134,6 +133,5 @@ def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle(own):
             got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True, engine=True)
     else:
         got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True)
-    ref = parity.per_sample_oracle(state, x, masks, N, 8, 8)
-    anchor = parity.per_sample_oracle(state, x, masks, N, 8, 8, bf16=True)
+    ref, anchor = parity.cached_oracle("c3_per_sample", state, x, masks, N, 8, 8, fn=parity.per_sample_oracle)
     parity.compare(got, ref, anchor, tol=1e-2)

@@ -51,9 +51,9 @@ def test_vitb_full_step_vs_oracle(mode):
         row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
         masks[d] = row[None].repeat(B, 1)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    ref = parity.oracle_step(state, x, masks, N, VITB["heads"], VITB["decoder_heads"])
     autocast = mode == "bf16"
-    anchor = parity.oracle_step(state, x, masks, N, VITB["heads"], VITB["decoder_heads"], bf16=True) if autocast else None
+    # (seeded construction: the library and own-GEMM cases see identical weights / inputs / masks and share the oracle's two runs)
+    ref, anchor = parity.cached_oracle(("vitb_full_step", mode), state, x, masks, N, VITB["heads"], VITB["decoder_heads"], anchor=autocast)
     model.to(DEV).train()
     xd = {k: v.to(DEV) for k, v in x.items()}; md = {k: v.to(DEV) for k, v in masks.items()}
     if own:
