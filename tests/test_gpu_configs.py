@@ -135,3 +135,41 @@ def test_c3_vitb_per_sample_dropout_bf16_step_with_gradients_vs_oracle(own):
         got = parity.native_step_flat(model, xd, {d: tm[d] for d in O.DOMAINS}, N, autocast=True)
     ref, anchor = parity.cached_oracle("c3_per_sample", state, x, masks, N, 8, 8, fn=parity.per_sample_oracle)
     parity.compare(got, ref, anchor, tol=1e-2)
+
+
+ODD_FFI = dict(dim_tokens=512, depth=2, dim_head=64, heads=8, image_size=128, patch_size=16, decoder_dim=64, decoder_depth=1, decoder_heads=2)
+
+
+@pytest.mark.parametrize("own", [False, True], ids=["library", "padded-owngemm"])
+def test_odd_geglu_width_padded_route_vs_oracle(own, monkeypatch):
+    """A token width whose GEGLU width fits none of the own GEMM's tiles (D = 512: ffi = int(512 * 8 / 3) = 1365 -> padded to 1536; ViT-L's
+    2730 -> 2816 runs in the ViT-L tests): the whole step on the padded route (ops._FeedForwardGEGLU over engine.padded_ff: FF1 + GEGLU,
+    FF2 and both input-gradient GEMMs on gemm8p_kernel, weight gradients at the exact width into the flat buffer) against the oracle --
+    every output, loss and gradient; the library case shares the oracle's runs."""
+    from incomplete_multimodal_fusion_amd import ops
+    from tests.test_cabi_symbols import build_model
+    torch.manual_seed(51)
+    channels = (("s1", 1), ("s2", 3), ("dem", 1))
+    model = build_model(ODD_FFI, channels)
+    assert model.blocks[0].mlp[3].weight.shape[1] == 1365
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad and (n.endswith("gamma") or "norm" in n and n.endswith("weight")):
+                p.add_(0.1 * torch.randn_like(p))
+        model.mask_embedding.add_(0.05 * torch.randn_like(model.mask_embedding))
+    B, P = 6, 64
+    x = {d: torch.randn(B, c, 128, 128) for d, c in channels}
+    masks = _masks(P, B, {"s1": 37, "s2": 30, "dem": 29})
+    N = 96
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref, anchor = parity.cached_oracle("odd_ffi", state, x, masks, N, 8, 2)
+    model.to(DEV).train()
+    xd, md = {k: v.to(DEV) for k, v in x.items()}, {k: v.to(DEV) for k, v in masks.items()}
+    if own:
+        monkeypatch.setattr(ops, "PAD_FF_MIN_TILES", 0)
+        with parity.own_gemm_engaged():
+            got = parity.native_step_flat(model, xd, md, N, True, engine=True)
+        assert len(model._parity_engine._pad) == 4            # 2 layers x (Block, Block_Fusion) FeedForwards registered padded copies
+    else:
+        got = parity.native_step_flat(model, xd, md, N, True)
+    parity.compare(got, ref, anchor, tol=1e-2)

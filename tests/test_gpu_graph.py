@@ -161,3 +161,41 @@ def test_failed_capture_leaves_the_step_eager_and_unchanged():
     step.capture(x, None)
     with pytest.raises(RuntimeError, match="already captured"):
         step.capture(x, None)
+
+
+def test_captured_step_with_padded_feedforward_replays_bitwise(monkeypatch):
+    """The padded-FeedForward route (odd GEGLU width on the own GEMM: engine.padded_ff) inside a captured step: the refresh of the padded
+    copies (mmae_pad_copy_bf16_batched) is one of the captured launches, so the replays must track the weight updates exactly like the
+    eager steps -- losses and optimizer state bitwise equal."""
+    from incomplete_multimodal_fusion_amd import ops
+    from incomplete_multimodal_fusion_amd.engine import FlatAdamW
+    from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    from tests.test_cabi_symbols import build_model
+    from tests.test_gpu_configs import ODD_FFI
+    monkeypatch.setattr(ops, "_OWN_GEMM_MIN_TILES", 0)
+    monkeypatch.setattr(ops, "PAD_FF_MIN_TILES", 0)
+    torch.manual_seed(13)
+    channels = (("s1", 1), ("s2", 3), ("dem", 1))
+    base = build_model(ODD_FFI, channels)
+    B, P = 8, 64
+    x = {d: torch.randn(B, c, 128, 128, device=DEV) for d, c in channels}
+    masks = {}
+    for d, k in (("s1", 40), ("s2", 30), ("dem", 26)):
+        row = torch.ones(P, dtype=torch.long); row[torch.randperm(P)[:k]] = 0
+        masks[d] = row[None].repeat(B, 1).to(DEV)
+
+    def make():
+        model = copy.deepcopy(base).to(DEV).train()
+        opt = FlatAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, exclude=model.never_used_parameters())
+        return model, opt, PretrainStep(model, opt, 96, clip_grad=0.5, check_finite=True)
+    _, opt_e, step_e = make()
+    _, opt_g, step_g = make()
+    losses = [step_e(x, task_masks=masks)["loss"].clone() for _ in range(5)]
+    assert len(opt_e._pad) == 4, "the padded route must be the one that ran"
+    step_g.capture(x, masks, warmup=2)
+    for i in range(2, 5):
+        out = step_g.replay()
+        assert torch.equal(out["loss"], losses[i]), (i, float(out["loss"]), float(losses[i]))
+    assert torch.equal(opt_g.master, opt_e.master) and torch.equal(opt_g.shadow, opt_e.shadow)
+    pe, pg = list(opt_e._pad.values()), list(opt_g._pad.values())
+    assert all(torch.equal(a.w1p, b.w1p) and torch.equal(a.w2pt, b.w2pt) for a, b in zip(pe, pg))
