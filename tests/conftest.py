@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    # The CPU oracle is most of the parity tests' time.  torch sizes its thread pool by the CPUs it can SEE; a GPU box shows all of the
+    # host's hardware threads but grants a 1-GPU lease a share of 16 cores, and an oversubscribed pool runs the oracle several times
+    # slower (bench.py's cpu_baseline caps its threads the same way).
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, 16)))
 
 
 class Golden:
