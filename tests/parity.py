@@ -146,25 +146,12 @@ def per_sample_oracle(state, x, masks, N, heads, dec_heads, bf16=False, domains=
     return {k: v.detach().double().cpu() for k, v in flat.items()}
 
 
-def chunked_oracle(state, x, masks, N, heads, dec_heads, chunk=8, bf16=False, domains=O.DOMAINS, device=None):
+def chunked_oracle(state, x, masks, N, heads, dec_heads, chunk=8, bf16=False, domains=O.DOMAINS):
     """The oracle's step on a LARGE batch with batch-shared masks, evaluated `chunk` samples at a time (the batched oracle keeps
     every (B, h, S, S) score matrix for its backward: ~0.9 GB per layer at B = 64).  Exact, not an approximation: every loss term of
     the step is a mean over samples -- the masked task losses are per-sample ratios averaged over the batch (criterion.py:107-111; no
     row of a shared mask with live modalities is empty), the DINO term a mean over rows (criterion.py:330-334) -- so the batch loss
-    is the sample-weighted mean of the chunk losses and the gradient the same mean of the chunk gradients.
-    device="cuda": evaluate the oracle's torch code with its tensors on the GPU (factory calls inside it follow torch.device(...)) --
-    ONLY for a bf16 ANCHOR, which is a noise scale and not a reference: the CPU's bf16 matmuls take ~4 minutes for 64 ViT-B samples."""
-    if device is not None:
-        assert bf16, "the reference itself is always the CPU oracle"
-        state = {k: v.to(device) for k, v in state.items()}
-        x = {k: v.to(device) for k, v in x.items()}
-        masks = {k: v.to(device) for k, v in masks.items()}
-        with torch.device(device):
-            return _chunked_oracle(state, x, masks, N, heads, dec_heads, chunk, bf16, domains, torch.device(device).type)
-    return _chunked_oracle(state, x, masks, N, heads, dec_heads, chunk, bf16, domains, "cpu")
-
-
-def _chunked_oracle(state, x, masks, N, heads, dec_heads, chunk, bf16, domains, autocast_device):
+    is the sample-weighted mean of the chunk losses and the gradient the same mean of the chunk gradients."""
     B = x[domains[0]].shape[0]
     assert all(int(masks[d][0].sum()) > 0 for d in domains), "chunking needs every modality to have masked patches (no empty mask row)"
     p = leaf_params(state)
@@ -173,7 +160,7 @@ def _chunked_oracle(state, x, masks, N, heads, dec_heads, chunk, bf16, domains, 
         xb = {k: v[a:a + chunk] for k, v in x.items()}
         mb = {k: v[a:a + chunk] for k, v in masks.items()}
         w = xb[domains[0]].shape[0] / B
-        out, (tl, lc, l) = O.train_step_loss(p, xb, mb, N, heads, dec_heads, 16, domains=domains, bf16=bf16, autocast_device=autocast_device)
+        out, (tl, lc, l) = O.train_step_loss(p, xb, mb, N, heads, dec_heads, 16, domains=domains, bf16=bf16)
         (l * w).backward()                                        # gradients accumulate over the chunks
         for d in domains:
             task_sum[d] += w * float(tl[d])
