@@ -492,6 +492,12 @@ extern "C" long mmae_mha_bwd_ws_floats(int H, long q_rows_total) {
     return (H <= 0 || q_rows_total <= 0) ? MMAE_ERR_ARG : 3L * H * q_rows_total;
 }
 
+// workspace of variant 50 (fused dQ + dK + dV kernel): the three planes + one fp32 64 x 64 partial per (sample, query tile, head)
+extern "C" long mmae_mha_bwd_fused_ws_floats(int B, int H, int nseg, long q_rows_total, int max_q_rows) {
+    if (B <= 0 || H <= 0 || nseg <= 0 || q_rows_total <= 0 || max_q_rows < 0) return MMAE_ERR_ARG;
+    return 3L * H * q_rows_total + (long)B * (max_q_rows / 64 + nseg) * H * 4096;
+}
+
 extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
                             const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk,
                             void* dv, long q_stride, long k_stride, long v_stride, long o_stride, long do_stride,
@@ -515,6 +521,10 @@ extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int n
     d.scale = scale; d.empty_mode = empty_mode;
     if (variant > 0) { d.hpb_req = (variant >> 8) & 15; variant &= 255; }
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
+    if (variant == 50) {          // fused backward (mha_sh_bwd_kernel): the workspace continues behind the three planes -- mmae_mha_bwd_fused_ws_floats
+        d.dq_ws = delta_ws + 3L * H * q_rows_total;
+        d.max_qt = mq;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, variant, st);
     return head_dim == 64 ? launch_bwd<float, 64>(d, mq, mk, st) : launch_bwd<float, 32>(d, mq, mk, st);

@@ -20,6 +20,8 @@ struct MhaDesc {
     int empty_mode;
     int hpb_req;             // sample-head kernels: heads one workgroup walks; 0 = chosen from (B, H) (tests force 1 / 2 / H through
                              // bits 8..11 of the `variant` argument of mmae_internal.h)
+    float* dq_ws;            // fused backward (mha_sh_bwd_kernel): fp32 partial dQ tiles, B x max_qt x H x 4096 floats (else null)
+    int max_qt;              // its tile slots per sample: upper bound of a sample's 64-row query tiles
 };
 
 struct TileSel { int seg, t0, n; };
@@ -62,4 +64,6 @@ int mha_sh_fwd(const MhaDesc& d, int mode, hipStream_t st);
 bool mha_sh_dkdv_supported(const MhaDesc& d);
 bool mha_sh_dq_supported(const MhaDesc& d);
 int mha_sh_dq(const MhaDesc& d, int mode, hipStream_t st);
+bool mha_sh_fused_supported(const MhaDesc& d);
+int mha_sh_bwd_fused(const MhaDesc& d, hipStream_t st);         // dQ + dK + dV in one kernel (+ the row-constant pre-pass); needs d.dq_ws
 int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st);   // needs workspace planes 1, 2 (see mha_bf16_bwd_dq_kernel)   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics

@@ -30,6 +30,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -1120,6 +1121,400 @@ __global__ __launch_bounds__(SQ_W * 64) void mha_sh_dq_kernel(MhaDesc p, int hpb
     }
 }
 
+// ------------------------------------------------------------------------------------------------------ backward: dQ + dK + dV fused
+// ONE key-stationary kernel for the whole backward (cdna_hip_programming.md, "Attention backward": five tile products -- S = Q K~^T and
+// dP = dO V^T once, dV^T += dO^T P, dK^T += Q^T dS, dQ += dS K -- instead of the seven of the dQ + dK/dV kernel pair).  Built on
+// mha_sh_dkdv_kernel: a wave owns 32 keys of the current pass (K / V fragments and dK^T / dV^T accumulators in registers) and the
+// workgroup sweeps the 64-row query tiles that may attend them.  What dQ adds:
+//   * dS sits with the KEY on the lane (the layout dK^T / dV^T contract over) while dQ contracts over keys: every wave writes its
+//     64 q x 32 k block of dS, as [key][q], into one LDS image of the step (dsx, swizzled like the tiles); after a second workgroup
+//     barrier waves 0..3 each own one 32 d x 32 q quarter of the tile's dQ^T and sum  K^T dS^T  over the key blocks that took part,
+//     both operands by transposed reads -- the K rows from images that stay resident for the whole pass (kimg);
+//   * the LDS this needs (64 KB of K images, double-buffered so the next pass's keys arrive under the current pass, + 32 KB of dS)
+//     does not fit beside twelve waves' staging: EIGHT waves (256 keys per pass), V of the next pass prefetched into registers
+//     instead of LDS (two waves per SIMD leave room), ring of three (Q, dO) tiles: 146 KB;
+//   * a query tile met in several passes (the fusion queries see every key) carries its fp32 dQ^T partial from pass to pass through
+//     a workspace slot private to the (tile, head): written by the first pass, prefetched as the accumulator's start value by the
+//     later ones, the last pass stores bf16 -- same workgroup, program order, so the sum is bitwise reproducible without atomics;
+//   * the row constants (-lse log2 e, -delta) come from a pre-pass (mha_rowconst_kernel: delta = rowsum(dO o O), one HBM pass over
+//     O and dO) -- the dQ kernels used to produce them on the way.
+// Loader waves of the (Q, dO) ring are 4..7: they skip the dQ phase, and waves 0..3 then never have ring DMA outstanding behind
+// the plain loads of a partial (hipcc waits vmcnt(0) for those).
+#define SB_NS 3
+#define SB_D 2
+#define SB_W 8
+#define SB_MAXB 64
+#define SB_MAXS 64
+
+__global__ __launch_bounds__(256) void mha_rowconst_kernel(MhaDesc p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = i / p.H;
+    const int h = (int)(i - row * p.H);
+    if (row >= p.stat_stride) return;
+    const bf16* o = reinterpret_cast<const bf16*>(p.o) + row * p.o_stride + h * 64;
+    const bf16* d = reinterpret_cast<const bf16*>(p.dout) + row * p.do_stride + h * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + 8 * c), b = *reinterpret_cast<const bf16x8*>(d + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+    }
+    const long at = (long)h * p.stat_stride + row, plane = (long)p.H * p.stat_stride;
+    p.delta[at] = acc; p.delta[at + plane] = -p.lse[at] * SH_LOG2E; p.delta[at + 2 * plane] = -acc;
+}
+
+__global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hpb) {
+    __shared__ __attribute__((aligned(1024))) bf16 ringQ[SB_NS][4096];
+    __shared__ __attribute__((aligned(1024))) bf16 ringO[SB_NS][4096];
+    __shared__ __attribute__((aligned(1024))) float ringL[SB_NS][128];       // [0..63] -lse2, [64..127] -delta of the tile's rows
+    __shared__ __attribute__((aligned(1024))) bf16 kimg[2][SB_W][2048];      // K images of the current / the next pass (one 32-key block per wave)
+    __shared__ __attribute__((aligned(1024))) bf16 dsx[SB_W * 2048];         // dS of the step: [32 w + key][64 q]
+    __shared__ int kb_row_s[SB_MAXB], kb_info_s[SB_MAXB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = sh_uni(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const int hgroups = p.H / hpb;
+    const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * hpb;
+    const int nseg = p.nseg, fus = nseg - 1;
+    ShSeg st; st.load(p, b, lane);
+    // ---- schedule of this sample (registers, one lane per entry)
+    // key blocks: first row, n | seg << 8.
+    // steps: first query row, tile slot, n | seg << 8 | mode << 12 | pass << 16 | last-of-pass << 24 | first pass of the tile << 25 | last pass << 26
+    // mode 1: ordinary tile, 2: fully masked query rows attending every key uniformly (P = 1 / keys, dS = 0), 3: no-op filler
+    int kb_row = 0, kb_info = 0, st_row = 0, st_info = 0, st_tid = 0, NB = 0, nsteps = 0, npass = 0;
+    {
+        for (int s = 0; s < nseg; ++s) {
+            const int L = st.kl(s), nb = (L + 31) >> 5, j = lane - NB;
+            if (j >= 0 && j < nb) { kb_row = st.ks(s) + 32 * j; kb_info = min(32, L - 32 * j) | (s << 8); }
+            NB += nb;
+        }
+        NB = min(NB, SB_MAXB);
+        npass = (NB + SB_W - 1) / SB_W;
+        if (wave == 0) { kb_row_s[lane] = kb_row; kb_info_s[lane] = kb_info; }
+        // first / last pass in which a segment's keys appear (4 bits each)
+        unsigned firstp = 0, lastp = 0, seen = 0;
+        for (int ps = 0; ps < npass; ++ps)
+            for (int w = 0; w < SB_W; ++w) {
+                const int kbi = SB_W * ps + w;
+                if (kbi < NB) {
+                    const int s = (__builtin_amdgcn_readlane(kb_info, kbi) >> 8) & 15;
+                    if (!((seen >> s) & 1)) { seen |= 1u << s; firstp |= (unsigned)ps << (4 * s); }
+                    lastp = (lastp & ~(15u << (4 * s))) | ((unsigned)ps << (4 * s));
+                }
+            }
+        for (int ps = 0; ps < npass; ++ps) {
+            int segmask = 0;
+            for (int w = 0; w < SB_W; ++w) {
+                const int kbi = SB_W * ps + w;
+                if (kbi < NB) segmask |= 1 << ((__builtin_amdgcn_readlane(kb_info, kbi) >> 8) & 15);
+            }
+            const int first = nsteps;
+            int tbase = 0;
+            for (int sq = 0; sq < nseg; ++sq) {
+                const int QL = st.ql(sq), nt = (QL + 63) >> 6;
+                const int tb = tbase;
+                tbase += nt;
+                if (QL == 0) continue;
+                int mode = 0;
+                if (sq == fus) mode = 1;
+                else if (st.kl(sq) > 0) mode = (segmask >> sq) & 1;
+                else if (p.empty_mode == 0) mode = 2;
+                if (!mode) continue;
+                // passes of this tile's dQ: the fusion queries meet every pass, a modality's queries the passes that hold its keys
+                const int fp = sq == fus ? 0 : (int)((firstp >> (4 * sq)) & 15), lp = sq == fus ? npass - 1 : (int)((lastp >> (4 * sq)) & 15);
+                const int j = lane - nsteps;
+                if (j >= 0 && j < nt) {
+                    st_row = st.qs(sq) + 64 * j; st_tid = tb + j;
+                    st_info = min(64, QL - 64 * j) | (sq << 8) | (mode << 12) | (ps << 16) | ((ps == fp ? 1 : 0) << 25) | ((ps == lp ? 1 : 0) << 26);
+                }
+                nsteps += nt;
+            }
+            if (nsteps == first) {                                 // a pass without queries still writes its (zero) gradients
+                if (lane == nsteps) { st_row = 0; st_tid = 0; st_info = (3 << 12) | (ps << 16); }
+                ++nsteps;
+            }
+            if (lane == nsteps - 1) st_info |= 1 << 24;
+        }
+        nsteps = min(nsteps, SB_MAXS);
+    }
+    __syncthreads();
+    // query rows whose dQ is zero by construction: no keys at all, or an empty key segment (zeros, or the uniform rows: dS = 0)
+    for (int hi = 0; hi < hpb; ++hi)
+        for (int s = 0; s < nseg; ++s) {
+            const int QL = st.ql(s);
+            if (QL > 0 && (NB == 0 || (s < fus && st.kl(s) == 0))) {
+                const long row0 = st.qs(s);
+                for (int i = tid; i < QL * 8; i += SB_W * 64)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.dq) + (row0 + (i >> 3)) * p.dq_stride + (h0 + hi) * 64 + 8 * (i & 7)) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    if (NB == 0) return;
+    auto s_row = [&](int i) { return __builtin_amdgcn_readlane(st_row, i); };
+    auto s_info = [&](int i) { return __builtin_amdgcn_readlane(st_info, i); };
+    auto s_tid = [&](int i) { return __builtin_amdgcn_readlane(st_tid, i); };
+
+    const bf16* qg = reinterpret_cast<const bf16*>(p.q);
+    const bf16* dog = reinterpret_cast<const bf16*>(p.dout);
+    const bf16* kg = reinterpret_cast<const bf16*>(p.k);
+    const bf16* vg = reinterpret_cast<const bf16*>(p.v);
+    const int qsb = (int)p.q_stride * 2, dosb = (int)p.do_stride * 2, ksb = (int)p.k_stride * 2, vsb = (int)p.v_stride * 2;
+    auto dma_voff = [&](int row_bytes, int z) { const int pr = (lane >> 3) + z; return pr * row_bytes + 16 * ((lane & 7) ^ sh_f(pr)); };
+    ShAddr ad; ad.init(lane);
+    const float cq = p.scale * SH_LOG2E;
+    const int G = hpb * nsteps;
+    int vm = 0, myseq = 0, mark = 0;
+    // ring: loader of step j is wave 4 + (j & 3) -- the waves that skip the dQ phase
+    int lj = 0, li = 0, lh = 0, lstage = 0;
+    auto issue_ring = [&]() {
+        if (wave == 4 + (lj & 3)) {
+            const long row0 = s_row(li); const int n = s_info(li) & 255, h = h0 + lh;
+            const bf16* qb_ = qg + row0 * p.q_stride + h * 64;
+            const bf16* ob_ = dog + row0 * p.do_stride + h * 64;
+            int z = 0;
+            asm volatile("" : "+s"(z));
+            const int qv = dma_voff(qsb, z), ov = dma_voff(dosb, z);
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                sh_dma(qb_, n, qsb, qv ^ (16 * (pc & 1)), 8 * pc * qsb, &ringQ[lstage][pc * 512]);
+                sh_dma(ob_, n, dosb, ov ^ (16 * (pc & 1)), 8 * pc * dosb, &ringO[lstage][pc * 512]);
+            }
+            const float* lp = p.delta + ((long)p.H + h) * p.stat_stride + row0;
+            const float* dp = p.delta + (2L * p.H + h) * p.stat_stride + row0;
+            sh_dma4(lp, n, &ringL[lstage][0], lane);
+            sh_dma4(dp, n, &ringL[lstage][64], lane);
+            vm += 18; myseq = vm;
+        }
+        ++lj;
+        if (++lstage == SB_NS) lstage = 0;
+        if (++li == nsteps) { li = 0; ++lh; }
+    };
+    auto kb_of = [&](int ps) { return SB_W * ps + wave; };
+    // next pass's key block: K rows -> kimg[buf][wave] (LDS-DMA), V rows -> registers in the operand layout (rows >= n read as zero)
+    bf16x8 vnext[4];
+    auto issue_kv = [&](int ps, int h, int buf) {
+        const int kbi = kb_of(ps);
+        const long row0 = sh_uni(kb_row_s[kbi]); const int n = sh_uni(kb_info_s[kbi]) & 255;
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const int kv_ = dma_voff(ksb, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh_dma(kg + row0 * p.k_stride + h * 64, n, ksb, kv_ ^ (16 * (j & 1)), 8 * j * ksb, &kimg[buf][wave][8 * j * 64]);
+        const bf16* vb = vg + row0 * p.v_stride + h * 64;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(vb);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        bf16* ub = reinterpret_cast<bf16*>(((unsigned long long)hi << 32) | lo);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, sh_uni(n * vsb), 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            vnext[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (r + z) * vsb + 32 * ks + 16 * hh, 0, 0));
+        vm += 8;
+    };
+
+    bf16x8 kf[4], vf[4];
+    f32x16 dk[2], dv[2];
+    int my_seg = -1, my_row = 0, my_n = 0;
+    bool have = false;
+    unsigned pass_segs = 0;                                        // 4 bits per wave of the pass: the segment of its key block, 15 = none
+    const int dq_d = wave & 1, dq_q = (wave >> 1) & 1;             // waves 0..3: their quarter of the dQ^T tile (32 d x 32 q)
+    const int dsw = (32 * wave + r) * 64, dsf = sh_f(r);
+
+    // ---- prologue
+    int nxt_ps = 0, nxt_h = 0, cur_buf = 0, nxt_buf = 0;
+    bool nxt_valid = kb_of(0) < NB;
+    if (nxt_valid) issue_kv(0, h0, 0);
+    mark = vm;
+    for (int i = 0; i < SB_D && i < G; ++i) issue_ring();
+
+    int si = 0, hi = 0, stage = 0, cur_ps = -1;
+    for (int g = 0; g < G; ++g) {
+        if (wave == 4 + (g & 3)) sh_wait_vm(vm - myseq);
+        __builtin_amdgcn_s_barrier();
+        if (lj < G) issue_ring();
+        const int inf = s_info(si), qn = inf & 255, sq = (inf >> 8) & 15, mode = (inf >> 12) & 15, ps = (inf >> 16) & 255;
+        const bool last = (inf >> 24) & 1, tfirst = (inf >> 25) & 1, tlast = (inf >> 26) & 1;
+        const int h = h0 + hi;
+        if (ps != cur_ps) {                                        // first step of a pass: take over the staged key block
+            cur_ps = ps;
+            cur_buf = nxt_buf;
+            have = kb_of(ps) < NB;
+            if (have) {
+                int z = 0;
+                asm volatile("" : "+s"(z));
+                const int kbi = kb_of(ps);
+                const int ki = sh_uni(kb_info_s[kbi]);
+                my_row = sh_uni(kb_row_s[kbi]); my_n = ki & 255; my_seg = (ki >> 8) & 15;
+                sh_wait_vm(vm - mark);
+                const int kbase = ad.krow0 + z;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 raw = sh_ld8(&kimg[cur_buf][wave][0] + (kbase ^ (16 * ks)));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kf[ks][j] = (bf16)((float)raw[j] * cq);
+                    vf[ks] = vnext[ks];
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+            }
+            pass_segs = 0;
+            for (int w = 0; w < SB_W; ++w) {
+                const int kbi = SB_W * ps + w;
+                pass_segs |= (unsigned)(kbi < NB ? (sh_uni(kb_info_s[kbi]) >> 8) & 15 : 15) << (4 * w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // stage the key block of the next pass (or of pass 0 of the next head) into the other image buffer
+            nxt_ps = ps + 1; nxt_h = hi;
+            if (nxt_ps == npass) { nxt_ps = 0; ++nxt_h; }
+            nxt_valid = nxt_h < hpb && kb_of(nxt_ps) < NB;
+            nxt_buf = cur_buf ^ 1;
+            if (nxt_valid) { issue_kv(nxt_ps, h0 + nxt_h, nxt_buf); mark = vm; }
+        }
+        // key blocks of the pass that take part in this tile (wave-uniform bit mask): all of them for the fusion queries, the tile's
+        // own modality otherwise; uniform rows (mode 2) have dS = 0
+        unsigned pmask = 0;
+        if (mode == 1)
+            for (int w = 0; w < SB_W; ++w) {
+                const int sg = (pass_segs >> (4 * w)) & 15;
+                if (sg != 15 && (sq == fus || sg == sq)) pmask |= 1u << w;
+            }
+        const bool dq_wave = wave < 4 && mode == 1;
+        // dQ^T quarter of waves 0..3: starts from the tile's partial of the earlier passes (prefetched here, used after the barrier)
+        f32x16 dqa;
+        float* wsq = p.dq_ws + ((((long)b * p.max_qt + s_tid(si)) * p.H + h) * 4 + (2 * dq_d + dq_q)) * 1024 + 4 * lane;
+        if (dq_wave && !tfirst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(wsq + 256 * i);
+                dqa[4 * i] = v4[0]; dqa[4 * i + 1] = v4[1]; dqa[4 * i + 2] = v4[2]; dqa[4 * i + 3] = v4[3];
+            }
+            vm += 4;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dqa[i] = 0.f;
+        }
+        const bool part = have && (mode == 2 || (mode == 1 && (sq == fus || sq == my_seg)));
+        if (part) {
+            const bf16* Qs = ringQ[0]; const bf16* Os = ringO[0];
+            const int sel = stage * 4096;
+            const int rbase = ad.krow0 + sel, tbase = ad.tr00 + sel;
+            const float* Ls = &ringL[stage][0];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                bf16x8 pb[2], dsb[2];
+                {
+                    f32x16 sacc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(Ls + 32 * qb + 8 * j + 4 * hh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sacc[4 * j + i] = a[i];
+                    }
+                    if (mode == 1)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) sacc = sh_mma(sh_ld8(Qs + 2048 * qb + (rbase ^ (16 * ks))), kf[ks], sacc);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pb[s2][j] = (bf16)sh_exp2(sacc[8 * s2 + j]);
+                }
+                if (mode == 1) {
+                    f32x16 dpacc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(Ls + 64 + 32 * qb + 8 * j + 4 * hh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dpacc[4 * j + i] = c[i];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) dpacc = sh_mma(sh_ld8(Os + 2048 * qb + (rbase ^ (16 * ks))), vf[ks], dpacc);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dsb[s2][j] = (bf16)((float)pb[s2][j] * dpacc[8 * s2 + j]);
+                        // dS for the dQ phase: element j of this lane is query 32 qb + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3) of key (wave, r):
+                        // two 8-byte pieces of row 32 wave + r of the [key][q] image
+                        const u32x4 w4 = __builtin_bit_cast(u32x4, dsb[s2]);
+                        const int c0 = 4 * qb + 2 * s2;
+                        *reinterpret_cast<u32x2*>(dsx + dsw + 8 * (c0 ^ dsf) + 4 * hh) = u32x2{w4[0], w4[1]};
+                        *reinterpret_cast<u32x2*>(dsx + dsw + 8 * ((c0 + 1) ^ dsf) + 4 * hh) = u32x2{w4[2], w4[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) dsb[s2] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});     // uniform rows: dS = 0
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int ro = 64 * (32 * qb + 16 * s2);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        dv[d] = sh_mma(sh_tr(Os + ro, tbase ^ (32 * d), tbase ^ (32 * d + 520)), pb[s2], dv[d]);
+                        dk[d] = sh_mma(sh_tr(Qs + ro, tbase ^ (32 * d), tbase ^ (32 * d + 520)), dsb[s2], dk[d]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (last && have) {                                        // last step of the pass: this key block's gradients are complete
+            const bool valid = r < my_n;
+            bf16* dkp = reinterpret_cast<bf16*>(p.dk) + (long)(my_row + r) * p.dk_stride + h * 64 + 8 * hh;
+            bf16* dvp = reinterpret_cast<bf16*>(p.dv) + (long)(my_row + r) * p.dv_stride + h * 64 + 8 * hh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    unsigned a0 = sh_pack2(dk[d][4 * i] * p.scale, dk[d][4 * i + 1] * p.scale), a1 = sh_pack2(dk[d][4 * i + 2] * p.scale, dk[d][4 * i + 3] * p.scale);
+                    unsigned b0 = sh_pack2(dk[d][4 * i + 4] * p.scale, dk[d][4 * i + 5] * p.scale), b1 = sh_pack2(dk[d][4 * i + 6] * p.scale, dk[d][4 * i + 7] * p.scale);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+                    if (valid) *reinterpret_cast<u32x4*>(dkp + 32 * d + 8 * i) = u32x4{a0, a1, b0, b1};
+                    unsigned c0 = sh_pack2(dv[d][4 * i], dv[d][4 * i + 1]), c1 = sh_pack2(dv[d][4 * i + 2], dv[d][4 * i + 3]);
+                    unsigned e0 = sh_pack2(dv[d][4 * i + 4], dv[d][4 * i + 5]), e1 = sh_pack2(dv[d][4 * i + 6], dv[d][4 * i + 7]);
+                    auto r2 = __builtin_amdgcn_permlane32_swap(c0, e0, false, false); c0 = r2[0]; e0 = r2[1];
+                    auto r3 = __builtin_amdgcn_permlane32_swap(c1, e1, false, false); c1 = r3[0]; e1 = r3[1];
+                    if (valid) *reinterpret_cast<u32x4*>(dvp + 32 * d + 8 * i) = u32x4{c0, c1, e0, e1};
+                }
+            vm += 8;
+        }
+        // ---- dQ phase: every wave's dS block is in dsx, the pass's K images have been resident since its first step
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (dq_wave) {
+            const bf16* Kc = &kimg[cur_buf][0][0];
+            for (int w = 0; w < SB_W; ++w) {
+                if (!((pmask >> w) & 1)) continue;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int ro = 64 * (32 * w + 16 * ks);
+                    dqa = sh_mma(sh_tr(Kc + ro, ad.tr00 ^ (32 * dq_d), ad.tr00 ^ (32 * dq_d + 520)),
+                                 sh_tr(dsx + ro, ad.tr00 ^ (32 * dq_q), ad.tr00 ^ (32 * dq_q + 520)), dqa);
+                }
+            }
+            if (!tlast) {                                          // carry the partial to the tile's next pass
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(wsq + 256 * i) = f32x4{dqa[4 * i], dqa[4 * i + 1], dqa[4 * i + 2], dqa[4 * i + 3]};
+                vm += 4;
+            } else {
+                const int qr = 32 * dq_q + r;
+                const bool valid = qr < qn;
+                bf16* dqp = reinterpret_cast<bf16*>(p.dq) + (long)(s_row(si) + qr) * p.dq_stride + h * 64 + 32 * dq_d + 8 * hh;
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    unsigned a0 = sh_pack2(dqa[4 * i] * p.scale, dqa[4 * i + 1] * p.scale), a1 = sh_pack2(dqa[4 * i + 2] * p.scale, dqa[4 * i + 3] * p.scale);
+                    unsigned b0 = sh_pack2(dqa[4 * i + 4] * p.scale, dqa[4 * i + 5] * p.scale), b1 = sh_pack2(dqa[4 * i + 6] * p.scale, dqa[4 * i + 7] * p.scale);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+                    if (valid) *reinterpret_cast<u32x4*>(dqp + 8 * i) = u32x4{a0, a1, b0, b1};
+                }
+                vm += 2;
+            }
+        }
+        if (++stage == SB_NS) stage = 0;
+        if (++si == nsteps) { si = 0; ++hi; cur_ps = -1; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ host side
 static int sh_heads_per_block(int B, int H, int req) {
     // one workgroup per CU when the batch allows it: a block walks `hpb` heads of its sample (hpb divides H)
@@ -1174,6 +1569,24 @@ int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st) {
     if (mode == 1) MMAE_LAUNCH(mha_sh_dkdv_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_dkdv_kernel<2>, grid, blk, 0, st, d, hpb);
     else MMAE_LAUNCH(mha_sh_dkdv_kernel<0>, grid, blk, 0, st, d, hpb);
+    MMAE_CHECK_LAUNCH();
+    return MMAE_OK;
+}
+
+// fused backward (mha_sh_bwd_kernel) + its row-constant pre-pass
+bool mha_sh_fused_supported(const MhaDesc& d) {
+    const int nb = d.max_k_rows / 32 + d.nseg, passes = (nb + SB_W - 1) / SB_W;
+    return nb <= SB_MAXB && passes <= 15 && d.nseg <= MAXSEG && passes * (d.max_q_rows / 64 + d.nseg + 1) <= SB_MAXS && d.dq_ws != nullptr &&
+           d.max_qt >= d.max_q_rows / 64 + d.nseg;
+}
+
+int mha_sh_bwd_fused(const MhaDesc& d, hipStream_t st) {
+    if (!mha_sh_fused_supported(d)) return MMAE_ERR_ARG;
+    const long n = d.stat_stride * d.H;
+    MMAE_LAUNCH(mha_rowconst_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
+    MMAE_CHECK_LAUNCH();
+    const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
+    MMAE_LAUNCH(mha_sh_bwd_kernel, dim3(d.B * (d.H / hpb)), dim3(SB_W * 64), 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 # sizes).  With hpb = 2 / 8 every case runs H = 8 -- the head loop and the cross-head prefetch of the bench configuration.
 @pytest.mark.parametrize("T,variant,hpb", [(torch.float32, 0, 0), (torch.bfloat16, 0, 0), (torch.bfloat16, 2, 0), (torch.bfloat16, 4, 0),
                                            (torch.bfloat16, 5, 0), (torch.bfloat16, 23, 0), (torch.bfloat16, 0, 1), (torch.bfloat16, 0, 2),
-                                           (torch.bfloat16, 0, 8), (torch.bfloat16, 5, 2), (torch.bfloat16, 5, 8)])
+                                           (torch.bfloat16, 0, 8), (torch.bfloat16, 5, 2), (torch.bfloat16, 5, 8), (torch.bfloat16, 50, 0), (torch.bfloat16, 50, 2),
+                                           (torch.bfloat16, 50, 8)])
 def test_fuzz_attention_segments(T, variant, hpb):
     from incomplete_multimodal_fusion_amd import ops
     rng = random.Random(1234)

@@ -309,12 +309,12 @@ def dense_attention_ref(q, k, v, qseg, kseg, scale, empty_mode):
 # H, hpb: heads, and how many of them ONE workgroup of the sample-head kernels walks (0 = the product's choice, which is 1 at
 # these batch sizes).  The bench shape (B = 256, H = 8) runs hpb = 8: head loop, K/V ring prefetch ACROSS head boundaries;
 # hpb 2 / 8 at H = 8 reach exactly that code here (forward + dK/dV with variant 0, the query-stationary dQ with variant 5).
-HPB_CASES = [(torch.bfloat16, 64, v, 8, hpb) for v in (0, 5) for hpb in (1, 2, 8)]
+HPB_CASES = [(torch.bfloat16, 64, v, 8, hpb) for v in (0, 5, 50) for hpb in (1, 2, 8)]       # 50: dQ + dK + dV fused (mha_sh_bwd_kernel)
 
 
 @pytest.mark.parametrize("T,dh,variant,H,hpb", [(torch.float32, 64, 0, 3, 0), (torch.float32, 32, 0, 3, 0), (torch.bfloat16, 64, 0, 3, 0),
                                                 (torch.bfloat16, 32, 0, 3, 0), (torch.bfloat16, 64, 2, 3, 0), (torch.bfloat16, 64, 4, 3, 0),
-                                                (torch.bfloat16, 64, 5, 3, 0), (torch.bfloat16, 64, 23, 3, 0)] + HPB_CASES)
+                                                (torch.bfloat16, 64, 5, 3, 0), (torch.bfloat16, 64, 23, 3, 0), (torch.bfloat16, 64, 50, 3, 0)] + HPB_CASES)
 @pytest.mark.parametrize("empty_mode", [0, 1])
 def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant, H, hpb):
     from incomplete_multimodal_fusion_amd import ops
@@ -405,7 +405,7 @@ def _dirichlet_segments(B, N, P, M, gen):
     return start, lens
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0, 5, 50])
 def test_mha_bench_shape_dispatch_vs_fp64(variant):
     """The configuration bench.py runs: B = 256 samples x H = 8 heads x dh 64, every sample Dirichlet-ragged
     modality segments summing to 384 + 256 fusion rows, bf16, the PRODUCT dispatch (variant 0: one workgroup per sample walks all
@@ -637,7 +637,7 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     res = []
     # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path (dh 64: 32x32x16 forward), 2: the round-1
     # 16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ (the stamped diagnostic builds 8 / 9 exist in `make DIAG=1` only)
-    for variant in ((-1, 0, 2, 4, 5) if dh == 64 else (-1, 0)):
+    for variant in ((-1, 0, 2, 4, 5, 50) if dh == 64 else (-1, 0)):
         x = qkv.clone().requires_grad_()
         out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)
