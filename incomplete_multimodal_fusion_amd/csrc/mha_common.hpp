@@ -65,5 +65,5 @@ bool mha_sh_dkdv_supported(const MhaDesc& d);
 bool mha_sh_dq_supported(const MhaDesc& d);
 int mha_sh_dq(const MhaDesc& d, int mode, hipStream_t st);
 bool mha_sh_fused_supported(const MhaDesc& d);
-int mha_sh_bwd_fused(const MhaDesc& d, hipStream_t st);         // dQ + dK + dV in one kernel (+ the row-constant pre-pass); needs d.dq_ws
+int mha_sh_bwd_fused(const MhaDesc& d, int mode, hipStream_t st);   // dQ + dK + dV in one kernel (+ the row-constant pre-pass); needs d.dq_ws; mode 1..3: diagnostics
 int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st);   // needs workspace planes 1, 2 (see mha_bf16_bwd_dq_kernel)   // mode 0: product; 1 / 2: stream-only / compute-only diagnostics

@@ -1146,24 +1146,39 @@ __global__ __launch_bounds__(SQ_W * 64) void mha_sh_dq_kernel(MhaDesc p, int hpb
 #define SB_MAXB 64
 #define SB_MAXS 64
 
+// One workgroup = 32 rows x H heads (H <= 8): a lane owns one 16-byte piece of a (row, head)'s 64 values of O and dO (fully coalesced
+// reads: a row's heads are contiguous), eight lanes add up one (row, head), the 32 x H results go through LDS so that every plane is
+// written in runs of 32 consecutive rows.
 __global__ __launch_bounds__(256) void mha_rowconst_kernel(MhaDesc p) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long row = i / p.H;
-    const int h = (int)(i - row * p.H);
-    if (row >= p.stat_stride) return;
-    const bf16* o = reinterpret_cast<const bf16*>(p.o) + row * p.o_stride + h * 64;
-    const bf16* d = reinterpret_cast<const bf16*>(p.dout) + row * p.do_stride + h * 64;
-    float acc = 0.f;
+    __shared__ float res[8][33];
+    const int t = threadIdx.x, c = t & 7, h = (t >> 3) & 7;
+    const long plane = (long)p.H * p.stat_stride;
+    for (int pass = 0; pass < 8; ++pass) {                           // 4 rows per pass: 256 threads = 4 rows x 8 heads x 8 pieces
+        const int lr = 4 * pass + (t >> 6);
+        const long row = (long)blockIdx.x * 32 + lr;
+        float acc = 0.f;
+        if (row < p.stat_stride && h < p.H) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.o) + row * p.o_stride + h * 64 + 8 * c);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.dout) + row * p.do_stride + h * 64 + 8 * c);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + 8 * c), b = *reinterpret_cast<const bf16x8*>(d + 8 * c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+            for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+        }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (c == 0) res[h][lr] = acc;
     }
-    const long at = (long)h * p.stat_stride + row, plane = (long)p.H * p.stat_stride;
-    p.delta[at] = acc; p.delta[at + plane] = -p.lse[at] * SH_LOG2E; p.delta[at + 2 * plane] = -acc;
+    __syncthreads();
+    const int hh = t >> 5, lr = t & 31;                              // 8 heads x 32 rows
+    const long row = (long)blockIdx.x * 32 + lr;
+    if (hh < p.H && row < p.stat_stride) {
+        const long at = (long)hh * p.stat_stride + row;
+        const float d = res[hh][lr];
+        p.delta[at] = d; p.delta[at + plane] = -p.lse[at] * SH_LOG2E; p.delta[at + 2 * plane] = -d;
+    }
 }
 
+// MODE (diagnostic builds, never the product path; wrong dQ): 1 = no dS exchange and no dQ phase (the dK / dV part alone on eight waves),
+// 2 = dQ phase without the workspace traffic of the partials
+template <int MODE>
 __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hpb) {
     __shared__ __attribute__((aligned(1024))) bf16 ringQ[SB_NS][4096];
     __shared__ __attribute__((aligned(1024))) bf16 ringO[SB_NS][4096];
@@ -1314,7 +1329,7 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
     f32x16 dk[2], dv[2];
     int my_seg = -1, my_row = 0, my_n = 0;
     bool have = false;
-    unsigned pass_segs = 0;                                        // 4 bits per wave of the pass: the segment of its key block, 15 = none
+    int nvalid = 0;                                                // key blocks of the current pass (a prefix of the waves)
     const int dq_d = wave & 1, dq_q = (wave >> 1) & 1;             // waves 0..3: their quarter of the dQ^T tile (32 d x 32 q)
     const int dsw = (32 * wave + r) * 64, dsf = sh_f(r);
 
@@ -1357,11 +1372,7 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
             }
-            pass_segs = 0;
-            for (int w = 0; w < SB_W; ++w) {
-                const int kbi = SB_W * ps + w;
-                pass_segs |= (unsigned)(kbi < NB ? (sh_uni(kb_info_s[kbi]) >> 8) & 15 : 15) << (4 * w);
-            }
+            nvalid = min(SB_W, NB - SB_W * ps);                   // the pass's key blocks are waves 0 .. nvalid - 1
             __builtin_amdgcn_sched_barrier(0);
             // stage the key block of the next pass (or of pass 0 of the next head) into the other image buffer
             nxt_ps = ps + 1; nxt_h = hi;
@@ -1370,19 +1381,11 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             nxt_buf = cur_buf ^ 1;
             if (nxt_valid) { issue_kv(nxt_ps, h0 + nxt_h, nxt_buf); mark = vm; }
         }
-        // key blocks of the pass that take part in this tile (wave-uniform bit mask): all of them for the fusion queries, the tile's
-        // own modality otherwise; uniform rows (mode 2) have dS = 0
-        unsigned pmask = 0;
-        if (mode == 1)
-            for (int w = 0; w < SB_W; ++w) {
-                const int sg = (pass_segs >> (4 * w)) & 15;
-                if (sg != 15 && (sq == fus || sg == sq)) pmask |= 1u << w;
-            }
-        const bool dq_wave = wave < 4 && mode == 1;
+        const bool dq_wave = wave < 4 && mode == 1 && MODE != 1;
         // dQ^T quarter of waves 0..3: starts from the tile's partial of the earlier passes (prefetched here, used after the barrier)
         f32x16 dqa;
         float* wsq = p.dq_ws + ((((long)b * p.max_qt + s_tid(si)) * p.H + h) * 4 + (2 * dq_d + dq_q)) * 1024 + 4 * lane;
-        if (dq_wave && !tfirst) {
+        if (dq_wave && !tfirst && MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(wsq + 256 * i);
@@ -1394,6 +1397,12 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             for (int i = 0; i < 16; ++i) dqa[i] = 0.f;
         }
         const bool part = have && (mode == 2 || (mode == 1 && (sq == fus || sq == my_seg)));
+        if (MODE != 1 && mode == 1 && have && !part) {
+            // a key block that does not take part in this tile contributes dS = 0: the dQ phase then runs ONE branch-free chain over
+            // every block of the pass (its K rows are finite: staged keys, zero rows beyond a block's end)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x2*>(dsx + dsw + 8 * (c ^ dsf) + 4 * hh) = u32x2{0u, 0u};
+        }
         if (part) {
             const bf16* Qs = ringQ[0]; const bf16* Os = ringO[0];
             const int sel = stage * 4096;
@@ -1434,10 +1443,12 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
                         for (int j = 0; j < 8; ++j) dsb[s2][j] = (bf16)((float)pb[s2][j] * dpacc[8 * s2 + j]);
                         // dS for the dQ phase: element j of this lane is query 32 qb + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3) of key (wave, r):
                         // two 8-byte pieces of row 32 wave + r of the [key][q] image
-                        const u32x4 w4 = __builtin_bit_cast(u32x4, dsb[s2]);
-                        const int c0 = 4 * qb + 2 * s2;
-                        *reinterpret_cast<u32x2*>(dsx + dsw + 8 * (c0 ^ dsf) + 4 * hh) = u32x2{w4[0], w4[1]};
-                        *reinterpret_cast<u32x2*>(dsx + dsw + 8 * ((c0 + 1) ^ dsf) + 4 * hh) = u32x2{w4[2], w4[3]};
+                        if (MODE != 1) {
+                            const u32x4 w4 = __builtin_bit_cast(u32x4, dsb[s2]);
+                            const int c0 = 4 * qb + 2 * s2;
+                            *reinterpret_cast<u32x2*>(dsx + dsw + 8 * (c0 ^ dsf) + 4 * hh) = u32x2{w4[0], w4[1]};
+                            *reinterpret_cast<u32x2*>(dsx + dsw + 8 * ((c0 + 1) ^ dsf) + 4 * hh) = u32x2{w4[2], w4[3]};
+                        }
                     }
                 } else {
 #pragma unroll
@@ -1477,20 +1488,32 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             vm += 8;
         }
         // ---- dQ phase: every wave's dS block is in dsx, the pass's K images have been resident since its first step
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (MODE != 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if (dq_wave) {
             const bf16* Kc = &kimg[cur_buf][0][0];
-            for (int w = 0; w < SB_W; ++w) {
-                if (!((pmask >> w) & 1)) continue;
+            const int ka = ad.tr00 ^ (32 * dq_d), kb2 = ad.tr00 ^ (32 * dq_d + 520), sa = ad.tr00 ^ (32 * dq_q), sb2 = ad.tr00 ^ (32 * dq_q + 520);
+            if (nvalid == SB_W) {                                  // the usual pass: every wave holds a key block -- one unrolled chain of 16
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int ro = 64 * (32 * w + 16 * ks);
-                    dqa = sh_mma(sh_tr(Kc + ro, ad.tr00 ^ (32 * dq_d), ad.tr00 ^ (32 * dq_d + 520)),
-                                 sh_tr(dsx + ro, ad.tr00 ^ (32 * dq_q), ad.tr00 ^ (32 * dq_q + 520)), dqa);
-                }
+                for (int w = 0; w < SB_W; ++w)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int ro = 64 * (32 * w + 16 * ks);
+                        dqa = sh_mma(sh_tr(Kc + ro, ka, kb2), sh_tr(dsx + ro, sa, sb2), dqa);
+                    }
+            } else {
+                for (int w = 0; w < nvalid; ++w)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int ro = 64 * (32 * w + 16 * ks);
+                        dqa = sh_mma(sh_tr(Kc + ro, ka, kb2), sh_tr(dsx + ro, sa, sb2), dqa);
+                    }
             }
-            if (!tlast) {                                          // carry the partial to the tile's next pass
+            if (!tlast && MODE == 2) {
+                asm volatile("" :: "v"(dqa));                      // keep the products live
+            } else if (!tlast) {                                   // carry the partial to the tile's next pass
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<f32x4*>(wsq + 256 * i) = f32x4{dqa[4 * i], dqa[4 * i + 1], dqa[4 * i + 2], dqa[4 * i + 3]};
@@ -1576,17 +1599,22 @@ int mha_sh_dkdv(const MhaDesc& d, int mode, hipStream_t st) {
 // fused backward (mha_sh_bwd_kernel) + its row-constant pre-pass
 bool mha_sh_fused_supported(const MhaDesc& d) {
     const int nb = d.max_k_rows / 32 + d.nseg, passes = (nb + SB_W - 1) / SB_W;
-    return nb <= SB_MAXB && passes <= 15 && d.nseg <= MAXSEG && passes * (d.max_q_rows / 64 + d.nseg + 1) <= SB_MAXS && d.dq_ws != nullptr &&
+    return nb <= SB_MAXB && passes <= 15 && d.nseg <= MAXSEG && d.H <= 8 && passes * (d.max_q_rows / 64 + d.nseg + 1) <= SB_MAXS && d.dq_ws != nullptr &&
            d.max_qt >= d.max_q_rows / 64 + d.nseg;
 }
 
-int mha_sh_bwd_fused(const MhaDesc& d, hipStream_t st) {
+int mha_sh_bwd_fused(const MhaDesc& d, int mode, hipStream_t st) {
     if (!mha_sh_fused_supported(d)) return MMAE_ERR_ARG;
     const long n = d.stat_stride * d.H;
-    MMAE_LAUNCH(mha_rowconst_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d);
-    MMAE_CHECK_LAUNCH();
+    if (mode != 3) {
+        MMAE_LAUNCH(mha_rowconst_kernel, dim3((unsigned)((d.stat_stride + 31) / 32)), dim3(256), 0, st, d);
+        MMAE_CHECK_LAUNCH();
+    }
     const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
-    MMAE_LAUNCH(mha_sh_bwd_kernel, dim3(d.B * (d.H / hpb)), dim3(SB_W * 64), 0, st, d, hpb);
+    const dim3 grid(d.B * (d.H / hpb)), blk(SB_W * 64);
+    if (mode == 1) MMAE_LAUNCH(mha_sh_bwd_kernel<1>, grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH(mha_sh_bwd_kernel<2>, grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH(mha_sh_bwd_kernel<0>, grid, blk, 0, st, d, hpb);          // (mode 3: without the row-constant pre-pass -- stale planes, timing only)
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

@@ -741,7 +741,7 @@ class _MHA(torch.autograd.Function):
         gq = torch.empty_like(qt) if (qseg.covers_all and (not same or kseg.covers_all)) else torch.zeros_like(qt)
         gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
         # workspace: delta plus, for the bf16 kernels, the row constants of the key-stationary dK/dV kernel (3 planes of (H, rows))
-        if variant > 0 and (variant & 255) == 50:      # fused dQ + dK + dV kernel: planes + fp32 partial dQ tiles (csrc/mmae_internal.h)
+        if variant > 0 and 50 <= (variant & 255) <= 53:      # fused dQ + dK + dV kernel: planes + fp32 partial dQ tiles (csrc/mmae_internal.h)
             nws = _lib.lib().mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
         else:
             nws = _lib.lib().mmae_mha_bwd_ws_floats(H, lse.shape[1])
