@@ -22,11 +22,12 @@ extern "C" {
 
 #define MMAE_F32 0
 #define MMAE_BF16 1
-#define MMAE_ABI_VERSION 6   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
+#define MMAE_ABI_VERSION 7   /* 2: mmae_mha_fwd takes max_k_rows; the attention stamp / variant entry points moved to csrc/mmae_internal.h.  3: + mmae_add_ln_fwd_cast;
                                 mmae_mha_bwd's workspace delta_ws grew from (H, rows) to (3, H, rows) floats (see mmae_mha_bwd_ws_floats).  4: + mmae_scale_rows,
                                 mmae_mha_bwd_ws_floats, mmae_gemm_nt, mmae_gemm_geglu, mmae_gemm_tn, mmae_splitk_sum_multi.  5: the optimizer control block grew
                                 from 4 to 8 floats (mmae_adamw_control / _step_ctl read [4], [5]); + mmae_adamw_tick, mmae_mha_fwd_route.  6: + mmae_pad_copy_bf16_batched
-                                (additive: no existing signature changed) */
+                                (additive: no existing signature changed).  7: + mmae_mha_bwd_fused, mmae_mha_bwd_fused_supported, mmae_mha_bwd_fused_ws_floats
+                                (additive) */
 int mmae_abi_version(void);
 /* hipError_t of this thread's most recent launch that returned MMAE_ERR_LAUNCH (0: none); reading resets it. */
 int mmae_last_hip_error(void);
@@ -56,6 +57,21 @@ int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q,
                  long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
                  const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                  int empty_mode, void* stream);
+/* The same backward as ONE kernel (bf16, head_dim 64; autograd of DSI-MM/zorro_utils.py:181-193 again): dQ, dK and dV from five tile
+ * products -- S and dP once, key-stationary, dS handed through LDS for dQ (mha_sh_bwd_kernel) -- after a pre-pass that writes the row
+ * constants delta = rowsum(dO o O), -lse log2 e, -delta.  Arguments as mmae_mha_bwd; delta_ws must hold
+ * mmae_mha_bwd_fused_ws_floats(B, H, nseg, q_rows_total, max_q_rows) floats: the three planes plus one fp32 64 x 64 partial dQ tile
+ * per (sample, 64-row query tile, head), through which a query tile that meets several key passes (the fusion queries see every key)
+ * carries its sum from pass to pass -- same workgroup, program order: bitwise reproducible, no atomics.
+ * mmae_mha_bwd_fused_supported: 1 when these arguments fit the kernel's schedule tables (else use mmae_mha_bwd). */
+long mmae_mha_bwd_fused_ws_floats(int B, int H, int nseg, long q_rows_total, int max_q_rows);
+int mmae_mha_bwd_fused_supported(int dtype, int head_dim, int B, int H, int nseg, int max_q_rows, int max_k_rows);
+int mmae_mha_bwd_fused(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                       const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                       long q_stride, long k_stride, long v_stride, long o_stride, long do_stride, long dq_stride,
+                       long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
+                       const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
+                       int empty_mode, void* stream);
 
 /* ---- modality attention of Block_Fusion (DSI-MM/zorro_utils.py:252-256 on MM/multimae_crossattn.py:454-462) ---------
  * For each of the B*P (sample, patch) rows: the fusion query (row of q) attends `ns` = M+1 key/value rows of kv

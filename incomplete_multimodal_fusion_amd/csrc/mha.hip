@@ -492,10 +492,19 @@ extern "C" long mmae_mha_bwd_ws_floats(int H, long q_rows_total) {
     return (H <= 0 || q_rows_total <= 0) ? MMAE_ERR_ARG : 3L * H * q_rows_total;
 }
 
-// workspace of variant 50 (fused dQ + dK + dV kernel): the three planes + one fp32 64 x 64 partial per (sample, query tile, head)
+// workspace of the fused dQ + dK + dV kernel: the three planes + one fp32 64 x 64 partial per (sample, query tile, head)
 extern "C" long mmae_mha_bwd_fused_ws_floats(int B, int H, int nseg, long q_rows_total, int max_q_rows) {
     if (B <= 0 || H <= 0 || nseg <= 0 || q_rows_total <= 0 || max_q_rows < 0) return MMAE_ERR_ARG;
     return 3L * H * q_rows_total + (long)B * (max_q_rows / 64 + nseg) * H * 4096;
+}
+
+extern "C" int mmae_mha_bwd_fused_supported(int dtype, int head_dim, int B, int H, int nseg, int max_q_rows, int max_k_rows) {
+    if (dtype != MMAE_BF16 || head_dim != 64 || B <= 0 || H <= 0 || nseg <= 0 || max_q_rows < 0 || max_k_rows < 0) return 0;
+    MhaDesc d{};
+    d.B = B; d.H = H; d.nseg = nseg; d.max_q_rows = max_q_rows; d.max_k_rows = max_k_rows;
+    d.max_qt = max_q_rows / 64 + nseg;
+    d.dq_ws = reinterpret_cast<float*>(16);          // (any non-null value: the predicate only tests that a workspace was given)
+    return mha_sh_fused_supported(d) ? 1 : 0;
 }
 
 extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
@@ -521,13 +530,25 @@ extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int n
     d.scale = scale; d.empty_mode = empty_mode;
     if (variant > 0) { d.hpb_req = (variant >> 8) & 15; variant &= 255; }
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
-    if (variant >= 50 && variant <= 53) {          // fused backward (mha_sh_bwd_kernel): the workspace continues behind the three planes -- mmae_mha_bwd_fused_ws_floats
+    if (variant >= 50 && variant <= 54) {          // fused backward (mha_sh_bwd_kernel): the workspace continues behind the three planes -- mmae_mha_bwd_fused_ws_floats
         d.dq_ws = delta_ws + 3L * H * q_rows_total;
         d.max_qt = mq;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MMAE_BF16) return variant < 0 ? (head_dim == 64 ? launch_bwd<bf16, 64>(d, mq, mk, st) : launch_bwd<bf16, 32>(d, mq, mk, st)) : mha_bf16_bwd(d, head_dim, mq, mk, variant, st);
     return head_dim == 64 ? launch_bwd<float, 64>(d, mq, mk, st) : launch_bwd<float, 32>(d, mq, mk, st);
+}
+
+extern "C" int mmae_mha_bwd_fused(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,
+                                  const void* out, const void* dout, const float* lse, float* delta_ws, void* dq, void* dk,
+                                  void* dv, long q_stride, long k_stride, long v_stride, long o_stride, long do_stride,
+                                  long dq_stride, long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start,
+                                  const int* q_seg_len, const int* k_seg_start, const int* k_seg_len, int max_q_rows,
+                                  int max_k_rows, float scale, int empty_mode, void* stream) {
+    if (!mmae_mha_bwd_fused_supported(dtype, head_dim, B, H, nseg, max_q_rows, max_k_rows)) return MMAE_ERR_ARG;
+    return mmae_mha_bwd_variant(dtype, head_dim, B, H, nseg, q, k, v, out, dout, lse, delta_ws, dq, dk, dv, q_stride, k_stride,
+                                v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride, q_rows_total, q_seg_start,
+                                q_seg_len, k_seg_start, k_seg_len, max_q_rows, max_k_rows, scale, empty_mode, 50, stream);
 }
 
 extern "C" int mmae_mha_bwd(int dtype, int head_dim, int B, int H, int nseg, const void* q, const void* k, const void* v,

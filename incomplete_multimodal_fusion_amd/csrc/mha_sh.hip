@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             nxt_buf = cur_buf ^ 1;
             if (nxt_valid) { issue_kv(nxt_ps, h0 + nxt_h, nxt_buf); mark = vm; }
         }
-        const bool dq_wave = wave < 4 && mode == 1 && MODE != 1;
+        const bool dq_wave = wave < 4 && mode == 1 && MODE != 1 && MODE != 4;      // MODE 4: dS exchange and barrier, no dQ products
         // dQ^T quarter of waves 0..3: starts from the tile's partial of the earlier passes (prefetched here, used after the barrier)
         f32x16 dqa;
         float* wsq = p.dq_ws + ((((long)b * p.max_qt + s_tid(si)) * p.H + h) * 4 + (2 * dq_d + dq_q)) * 1024 + 4 * lane;
@@ -1614,6 +1614,7 @@ int mha_sh_bwd_fused(const MhaDesc& d, int mode, hipStream_t st) {
     const dim3 grid(d.B * (d.H / hpb)), blk(SB_W * 64);
     if (mode == 1) MMAE_LAUNCH(mha_sh_bwd_kernel<1>, grid, blk, 0, st, d, hpb);
     else if (mode == 2) MMAE_LAUNCH(mha_sh_bwd_kernel<2>, grid, blk, 0, st, d, hpb);
+    else if (mode == 4) MMAE_LAUNCH(mha_sh_bwd_kernel<4>, grid, blk, 0, st, d, hpb);
     else MMAE_LAUNCH(mha_sh_bwd_kernel<0>, grid, blk, 0, st, d, hpb);          // (mode 3: without the row-constant pre-pass -- stale planes, timing only)
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;

@@ -24,9 +24,9 @@ int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const 
                          long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
                          const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                          int empty_mode, int variant, void* stream);
-/* variant 50 of the backward (dQ + dK + dV fused, mha_sh.hip): floats of delta_ws it needs -- the three (H, rows) planes plus one fp32
- * 64 x 64 partial per (sample, 64-row query tile, head). */
-long mmae_mha_bwd_fused_ws_floats(int B, int H, int nseg, long q_rows_total, int max_q_rows);
+/* backward variants 50..54: the fused dQ + dK + dV kernel (product entry: mmae_mha_bwd_fused) and its diagnostic builds -- 51 no dQ part,
+ * 52 no partial-tile workspace traffic, 53 no row-constant pre-pass, 54 dS exchange without the dQ products (51..54: wrong dQ, timing only);
+ * delta_ws sized by mmae_mha_bwd_fused_ws_floats (include/mmae_hip.h). */
 /* diagnostic (variant 9 of the forward): copies the 8 per-launch stamp sums to host8 and clears them (host sync). */
 int mmae_debug_mha_stamps(unsigned long long* host8);
 /* diagnostic (variant 8 of the forward, mha_sh.hip): 2 x 16 stamp sums (global-role waves, local-role waves), cleared on read */

@@ -741,13 +741,16 @@ class _MHA(torch.autograd.Function):
         gq = torch.empty_like(qt) if (qseg.covers_all and (not same or kseg.covers_all)) else torch.zeros_like(qt)
         gkv = gq if same else (torch.empty_like(kv) if kseg.covers_all else torch.zeros_like(kv))
         # workspace: delta plus, for the bf16 kernels, the row constants of the key-stationary dK/dV kernel (3 planes of (H, rows))
-        if variant > 0 and 50 <= (variant & 255) <= 53:      # fused dQ + dK + dV kernel: planes + fp32 partial dQ tiles (csrc/mmae_internal.h)
-            nws = _lib.lib().mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
+        lib_ = _lib.lib()
+        fused = (not variant and MHA_FUSED_BWD and qt.dtype == torch.bfloat16 and dh == 64 and qseg.max_rows >= 128 and kseg.max_rows >= 128 and
+                 bool(lib_.mmae_mha_bwd_fused_supported(dt(qt), dh, qseg.B, H, qseg.nseg, qseg.max_rows, kseg.max_rows)))
+        if fused or (variant > 0 and 50 <= (variant & 255) <= 54):      # planes + fp32 partial dQ tiles
+            nws = lib_.mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
         else:
-            nws = _lib.lib().mmae_mha_bwd_ws_floats(H, lse.shape[1])
+            nws = lib_.mmae_mha_bwd_ws_floats(H, lse.shape[1])
         delta = torch.empty(nws, dtype=lse.dtype, device=lse.device)
         es = qt.element_size()
-        call("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd", dt(qt), dh, qseg.B, H, qseg.nseg,
+        call("mmae_mha_bwd_fused" if fused else ("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd"), dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
              ctypes.c_void_p(kv.data_ptr() + vcol * es), ptr(out), ptr(gout), ptr(lse), ptr(delta),
              ctypes.c_void_p(gq.data_ptr() + qcol * es), ctypes.c_void_p(gkv.data_ptr() + kcol * es),
@@ -759,6 +762,9 @@ class _MHA(torch.autograd.Function):
 
 
 MHA_SELF_VARIANT = 0       # variant of mha_self calls that pass none (0 = product kernels; tools/tuning_env.py sets it for A/B runs)
+MHA_FUSED_BWD = True       # bf16 / dh 64 calls with >= 128 query and key rows per sample (the encoder blocks) run their backward as ONE kernel
+                           # (mmae_mha_bwd_fused: dQ + dK + dV from five tile products) where its schedule tables fit; False: the dQ + dK/dV
+                           # kernel pair of mmae_mha_bwd everywhere.  Same-box A/B in the step: 154.4 -> 153.1 ms (tools/tuning_env.py: MMAE_MHA_FUSED_BWD)
 
 
 def _variant_word(variant: int, hpb: int) -> int:

@@ -10,7 +10,8 @@ from incomplete_multimodal_fusion_amd import _lib
 
 QUERIES = {"mmae_abi_version", "mmae_last_hip_error", "mmae_modattn_bwd_nsplit",
            "mmae_add_ln_bwd_ws_floats", "mmae_hardneg_ws_floats", "mmae_mha_bwd_ws_floats",
-           "mmae_gemm_nt_supported", "mmae_gemm_geglu_supported", "mmae_gemm_tn_supported", "mmae_gemm_tn_ws_floats"}           # setters / size / shape queries: no pointers to validate
+           "mmae_gemm_nt_supported", "mmae_gemm_geglu_supported", "mmae_gemm_tn_supported", "mmae_gemm_tn_ws_floats",
+           "mmae_mha_bwd_fused_supported", "mmae_mha_bwd_fused_ws_floats"}           # setters / size / shape queries: no pointers to validate
 
 
 def test_every_entry_point_rejects_null_pointers():

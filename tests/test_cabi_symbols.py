@@ -17,7 +17,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "missing export: " + name
-    assert _lib.lib().mmae_abi_version() == 6
+    assert _lib.lib().mmae_abi_version() == 7
     # pure host helpers (no GPU needed)
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(1000, 768) == 250 * 4 * 768
     assert _lib.lib().mmae_add_ln_bwd_ws_floats(40960, 768) == 1024 * 4 * 768

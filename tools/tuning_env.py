@@ -12,6 +12,7 @@ The product package reads NO tuning variable itself (only MMAE_HIP_LIB, the libr
     MMAE_OWN_GEMM        ops.OWN_GEMM               bit 0: own 8-phase GEMM for forward / input-gradient projections, bit 1: for weight gradients
     MMAE_ASYNC_DRAW      multimae_crossattn.ASYNC_DRAW_COPY   0: the mask draw's host->device copy from pageable memory (one host/GPU sync per step)
     MMAE_DEFER_SPLITK    ops.DEFER_SPLITK           0: one split-K sum launch per weight gradient instead of one per layer
+    MMAE_MHA_FUSED_BWD   ops.MHA_FUSED_BWD          0: the dQ + dK/dV kernel pair instead of the fused attention backward
     MMAE_PAD_FF_MIN_TILES ops.PAD_FF_MIN_TILES      output tiles of FeedForward[3] from which the padded route is taken
     MMAE_PAD_FF          ops.PAD_FF                 0: FeedForwards whose GEGLU width fits none of the own GEMM's tiles (ViT-L) stay on the library GEMMs
 """
@@ -37,6 +38,7 @@ def apply(verbose=True):
     put(ops, "OWN_GEMM", "MMAE_OWN_GEMM", int)
     put(ops, "DEFER_SPLITK", "MMAE_DEFER_SPLITK", flag)
     put(ops, "PAD_FF", "MMAE_PAD_FF", flag)
+    put(ops, "MHA_FUSED_BWD", "MMAE_MHA_FUSED_BWD", flag)
     put(ops, "PAD_FF_MIN_TILES", "MMAE_PAD_FF_MIN_TILES", int)
     put(mc, "FUSED_FINAL_CAST", "MMAE_FUSED_CAST", flag)
     put(mc, "FUSED_DECODER_CTX", "MMAE_FUSED_CTX", flag)
