@@ -1198,11 +1198,28 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
     // mode 1: ordinary tile, 2: fully masked query rows attending every key uniformly (P = 1 / keys, dS = 0), 3: no-op filler
     int kb_row = 0, kb_info = 0, st_row = 0, st_info = 0, st_tid = 0, NB = 0, nsteps = 0, npass = 0;
     {
-        for (int s = 0; s < nseg; ++s) {
-            const int L = st.kl(s), nb = (L + 31) >> 5, j = lane - NB;
-            if (j >= 0 && j < nb) { kb_row = st.ks(s) + 32 * j; kb_info = min(32, L - 32 * j) | (s << 8); }
-            NB += nb;
+        // Order of the key blocks over the passes (SB_W per pass; any order is correct: a block's pass only decides which query tiles
+        // it meets when).  A modality segment that would straddle a pass boundary although it fits one pass is pushed to the next pass
+        // and the gap is filled with FUSION key blocks -- their queries' tiles are swept in every pass anyway, while a straddling
+        // modality gets its query tiles swept twice, each time by a few waves only.
+        const int FB = (st.kl(fus) + 31) >> 5;
+        int fus_used = 0;
+        auto place = [&](int s, int first, int count) {           // blocks first .. first + count - 1 of segment s -> slots NB ..
+            const int j = lane - NB, L = st.kl(s);
+            if (j >= 0 && j < count) { kb_row = st.ks(s) + 32 * (first + j); kb_info = min(32, L - 32 * (first + j)) | (s << 8); }
+            NB += count;
+        };
+        for (int s = 0; s < fus; ++s) {
+            const int nb = (st.kl(s) + 31) >> 5;
+            if (nb == 0) continue;
+            const int room = (SB_W - NB % SB_W) % SB_W;
+            if (room > 0 && nb > room && nb <= SB_W) {
+                const int pad = min(room, FB - fus_used);
+                if (pad > 0) { place(fus, fus_used, pad); fus_used += pad; }
+            }
+            place(s, 0, nb);
         }
+        if (FB > fus_used) place(fus, fus_used, FB - fus_used);
         NB = min(NB, SB_MAXB);
         npass = (NB + SB_W - 1) / SB_W;
         if (wave == 0) { kb_row_s[lane] = kb_row; kb_info_s[lane] = kb_info; }
