@@ -1539,15 +1539,19 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
                 const int qr = 32 * dq_q + r;
                 const bool valid = qr < qn;
                 bf16* dqp = reinterpret_cast<bf16*>(p.dq) + (long)(s_row(si) + qr) * p.dq_stride + h * 64 + 32 * dq_d + 8 * hh;
+                // (a tile of <= 32 rows leaves the upper query half without a valid row: those waves issue no store, and `vm` must count
+                // exactly the vector-memory instructions issued -- an over-count would let a later counted wait return early)
+                if (qn > 32 * dq_q) {
 #pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    unsigned a0 = sh_pack2(dqa[4 * i] * p.scale, dqa[4 * i + 1] * p.scale), a1 = sh_pack2(dqa[4 * i + 2] * p.scale, dqa[4 * i + 3] * p.scale);
-                    unsigned b0 = sh_pack2(dqa[4 * i + 4] * p.scale, dqa[4 * i + 5] * p.scale), b1 = sh_pack2(dqa[4 * i + 6] * p.scale, dqa[4 * i + 7] * p.scale);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
-                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
-                    if (valid) *reinterpret_cast<u32x4*>(dqp + 8 * i) = u32x4{a0, a1, b0, b1};
+                    for (int i = 0; i < 4; i += 2) {
+                        unsigned a0 = sh_pack2(dqa[4 * i] * p.scale, dqa[4 * i + 1] * p.scale), a1 = sh_pack2(dqa[4 * i + 2] * p.scale, dqa[4 * i + 3] * p.scale);
+                        unsigned b0 = sh_pack2(dqa[4 * i + 4] * p.scale, dqa[4 * i + 5] * p.scale), b1 = sh_pack2(dqa[4 * i + 6] * p.scale, dqa[4 * i + 7] * p.scale);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r0[0]; b0 = r0[1];
+                        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r1[0]; b1 = r1[1];
+                        if (valid) *reinterpret_cast<u32x4*>(dqp + 8 * i) = u32x4{a0, a1, b0, b1};
+                    }
+                    vm += 2;
                 }
-                vm += 2;
             }
         }
         if (++stage == SB_NS) stage = 0;
