@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(SQ_W * 64) void mha_sh_dq_kernel(MhaDesc p, int hpb
 #define SB_D 2
 #define SB_W 8
 #define SB_MAXB 64
-#define SB_MAXS 64
+#define SB_MAXS 128
 
 // One workgroup = 32 rows x H heads (H <= 8): a lane owns one 16-byte piece of a (row, head)'s 64 values of O and dO (fully coalesced
 // reads: a row's heads are contiguous), eight lanes add up one (row, head), the 32 x H results go through LDS so that every plane is
@@ -1196,7 +1196,9 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
     // key blocks: first row, n | seg << 8.
     // steps: first query row, tile slot, n | seg << 8 | mode << 12 | pass << 16 | last-of-pass << 24 | first pass of the tile << 25 | last pass << 26
     // mode 1: ordinary tile, 2: fully masked query rows attending every key uniformly (P = 1 / keys, dS = 0), 3: no-op filler
-    int kb_row = 0, kb_info = 0, st_row = 0, st_info = 0, st_tid = 0, NB = 0, nsteps = 0, npass = 0;
+    // (the step table holds 2 x 64 entries: entry i lives on lane i & 63 of register set i >> 6)
+    int kb_row = 0, kb_info = 0, NB = 0, nsteps = 0, npass = 0;
+    int st_row[2] = {0, 0}, st_info[2] = {0, 0}, st_tid[2] = {0, 0};
     {
         // Order of the key blocks over the passes (SB_W per pass; any order is correct: a block's pass only decides which query tiles
         // it meets when).  A modality segment that would straddle a pass boundary although it fits one pass is pushed to the next pass
@@ -1254,18 +1256,25 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
                 if (!mode) continue;
                 // passes of this tile's dQ: the fusion queries meet every pass, a modality's queries the passes that hold its keys
                 const int fp = sq == fus ? 0 : (int)((firstp >> (4 * sq)) & 15), lp = sq == fus ? npass - 1 : (int)((lastp >> (4 * sq)) & 15);
-                const int j = lane - nsteps;
-                if (j >= 0 && j < nt) {
-                    st_row = st.qs(sq) + 64 * j; st_tid = tb + j;
-                    st_info = min(64, QL - 64 * j) | (sq << 8) | (mode << 12) | (ps << 16) | ((ps == fp ? 1 : 0) << 25) | ((ps == lp ? 1 : 0) << 26);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = lane + 64 * k - nsteps;
+                    if (j >= 0 && j < nt) {
+                        st_row[k] = st.qs(sq) + 64 * j; st_tid[k] = tb + j;
+                        st_info[k] = min(64, QL - 64 * j) | (sq << 8) | (mode << 12) | (ps << 16) | ((ps == fp ? 1 : 0) << 25) | ((ps == lp ? 1 : 0) << 26);
+                    }
                 }
                 nsteps += nt;
             }
             if (nsteps == first) {                                 // a pass without queries still writes its (zero) gradients
-                if (lane == nsteps) { st_row = 0; st_tid = 0; st_info = (3 << 12) | (ps << 16); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (lane + 64 * k == nsteps) { st_row[k] = 0; st_tid[k] = 0; st_info[k] = (3 << 12) | (ps << 16); }
                 ++nsteps;
             }
-            if (lane == nsteps - 1) st_info |= 1 << 24;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (lane + 64 * k == nsteps - 1) st_info[k] |= 1 << 24;
         }
         nsteps = min(nsteps, SB_MAXS);
     }
@@ -1281,9 +1290,9 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             }
         }
     if (NB == 0) return;
-    auto s_row = [&](int i) { return __builtin_amdgcn_readlane(st_row, i); };
-    auto s_info = [&](int i) { return __builtin_amdgcn_readlane(st_info, i); };
-    auto s_tid = [&](int i) { return __builtin_amdgcn_readlane(st_tid, i); };
+    auto s_row = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(st_row[0], i) : __builtin_amdgcn_readlane(st_row[1], i - 64); };
+    auto s_info = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(st_info[0], i) : __builtin_amdgcn_readlane(st_info[1], i - 64); };
+    auto s_tid = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(st_tid[0], i) : __builtin_amdgcn_readlane(st_tid[1], i - 64); };
 
     const bf16* qg = reinterpret_cast<const bf16*>(p.q);
     const bf16* dog = reinterpret_cast<const bf16*>(p.dout);

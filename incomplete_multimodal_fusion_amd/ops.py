@@ -743,6 +743,7 @@ class _MHA(torch.autograd.Function):
         # workspace: delta plus, for the bf16 kernels, the row constants of the key-stationary dK/dV kernel (3 planes of (H, rows))
         lib_ = _lib.lib()
         fused = (not variant and MHA_FUSED_BWD and qt.dtype == torch.bfloat16 and dh == 64 and qseg.max_rows >= 128 and kseg.max_rows >= 128 and
+                 (kseg.max_rows // 32 + kseg.nseg + 7) // 8 <= MHA_FUSED_MAX_PASSES and
                  bool(lib_.mmae_mha_bwd_fused_supported(dt(qt), dh, qseg.B, H, qseg.nseg, qseg.max_rows, kseg.max_rows)))
         if fused or (variant > 0 and 50 <= (variant & 255) <= 54):      # planes + fp32 partial dQ tiles
             nws = lib_.mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
@@ -765,6 +766,10 @@ MHA_SELF_VARIANT = 0       # variant of mha_self calls that pass none (0 = produ
 MHA_FUSED_BWD = True       # bf16 / dh 64 calls with >= 128 query and key rows per sample (the encoder blocks) run their backward as ONE kernel
                            # (mmae_mha_bwd_fused: dQ + dK + dV from five tile products) where its schedule tables fit; False: the dQ + dK/dV
                            # kernel pair of mmae_mha_bwd everywhere.  Same-box A/B in the step: 154.4 -> 153.1 ms (tools/tuning_env.py: MMAE_MHA_FUSED_BWD)
+MHA_FUSED_MAX_PASSES = 3   # ... and only while a sample's keys fit this many passes of 256 (upper bound from max_k_rows and the segment count): every
+                           # pass sweeps the fusion queries' tiles again and carries their fp32 partials through the workspace.  640 keys / 4
+                           # segments (the headline, ViT-L 3-modality): 3 passes, fused wins; config 5 (768 keys, 5 segments, per-sample
+                           # dropout): 4 passes, same-box A/B 146.9 (pair) vs 147.8 ms (fused) -> the pair
 
 
 def _variant_word(variant: int, hpb: int) -> int:

@@ -388,6 +388,43 @@ def test_mha_online_softmax_rescale_branch(T, variant, shift, H, hpb):
     close(out, ref, tol, "out"); close(qkv.grad, x.grad, tol * GRAD, "grads")
 
 
+def test_mha_fused_backward_long_schedule():
+    """The fused backward's step table holds 2 x 64 entries (one lane each of two register sets): samples whose schedule runs past
+    the first 64 steps -- many key passes, long segments -- against the fp64 restatement.  Sample 0: 5 passes, ~70 steps."""
+    from incomplete_multimodal_fusion_amd import ops
+    torch.manual_seed(9)
+    H, dh, nseg = 2, 64, 3
+    I = H * dh
+    lens = torch.tensor([[520, 10, 500], [300, 333, 257]], dtype=torch.int32)
+    B = lens.shape[0]
+    st = torch.zeros_like(lens); r = 0
+    for b in range(B):
+        for s_ in range(nseg):
+            st[b, s_] = r; r += int(lens[b, s_])
+    seg = ops.Segments(st.to(DEV), lens.to(DEV), int(lens.sum(1).max()))
+    assert _lib_fused_supported(B, H, nseg, seg.max_rows)
+    qkv = torch.randn(r, 3 * I, device=DEV).to(torch.bfloat16)
+    g = torch.randn(r, I, device=DEV).to(torch.bfloat16)
+    x = qkv.clone().requires_grad_()
+    out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=50)
+    out.backward(g)
+    xs = x.detach().cpu().double()
+    q64 = xs[:, :I].reshape(-1, H, dh).clone().requires_grad_()
+    k64 = xs[:, I:2 * I].reshape(-1, H, dh).clone().requires_grad_()
+    v64 = xs[:, 2 * I:].reshape(-1, H, dh).clone().requires_grad_()
+    ref = dense_attention_ref(q64, k64, v64, (st, lens), (st, lens), dh ** -0.5, 0)
+    ref.backward(g.cpu().double().reshape(-1, H, dh))
+    close(out, ref.reshape(-1, I), 1e-2, "out")
+    close(x.grad[:, :I], q64.grad.reshape(-1, I), 1e-2 * GRAD, "dq")
+    close(x.grad[:, I:2 * I], k64.grad.reshape(-1, I), 1e-2 * GRAD, "dk")
+    close(x.grad[:, 2 * I:], v64.grad.reshape(-1, I), 1e-2 * GRAD, "dv")
+
+
+def _lib_fused_supported(B, H, nseg, max_rows):
+    from incomplete_multimodal_fusion_amd import _lib
+    return bool(_lib.lib().mmae_mha_bwd_fused_supported(_lib.BF16, 64, B, H, nseg, max_rows, max_rows))
+
+
 def _dirichlet_segments(B, N, P, M, gen):
     """Per-sample segment lengths as the bench draws them: Dirichlet(1) shares of N kept tokens over M modalities (largest-remainder
     rounding so each row sums to N, capped at P) + P fusion rows.  -> (start, length) int32 (B, M + 1), rows packed per sample."""
