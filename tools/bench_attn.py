@@ -12,12 +12,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--H", type=int, default=8)
 ap.add_argument("--dh", type=int, default=64)
-ap.add_argument("--variants", default="0", help="0: product kernels (dh 64 forward = 32x32x16), 2: round-1 16x16x32 forward, 4: 256-query tiles")
+ap.add_argument("--variants", default="0", help="0: product kernels (dh 64 forward = 32x32x16, backward = the fused dQ + dK + dV kernel), 2: round-1 "
+                "16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ + dK/dV pair, 50: fused backward, 51-54: its diagnostics")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")
 ap.add_argument("--lib", default=None, help="another build of libmmae_hip.so (A/B runs inside one gpurun call)")
+ap.add_argument("--pair", action="store_true", help="variant 0 = the dQ + dK/dV kernel PAIR (ops.MHA_FUSED_BWD = False) instead of the fused "
+                "backward the product path runs; variant 50 is the fused kernel either way")
 a = ap.parse_args()
+if a.pair:
+    ops.MHA_FUSED_BWD = False
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = "cuda"
