@@ -73,6 +73,10 @@ __device__ __forceinline__ float gm_gelu(float x) {
 #endif
 }
 
+#ifndef GM_EPI_DIAG
+#define GM_EPI_DIAG 0             // 1 / 2 / 3: timing-only builds of the GEGLU epilogue (no GELU / no product store / h in 8-byte stores) for
+                                  // tools/probes/geglu_epi_probe.py -- wrong results by construction
+#endif
 struct GemmArgs {
     const bf16* A; const bf16* W; bf16* C; bf16* G;      // G: GEGLU product (EPI 1), else unused
     int M, N, K;                                         // EPI 1: N = F output pairs (W has 2 F rows: val rows [0, F), gate rows [F, 2 F))
@@ -194,11 +198,23 @@ __device__ __forceinline__ void store_half(const f32x4 (&acc)[8][4], const Lane&
                 // round them; the product is formed from those rounded values (= what geglu_fwd_kernel computes from h)
                 const unsigned hv = gm_pack2(acc[mi][0][reg], acc[mi][1][reg]), hg = gm_pack2(acc[mi][2][reg], acc[mi][3][reg]);
                 const bf16x2 bv = __builtin_bit_cast(bf16x2, hv), bg = __builtin_bit_cast(bf16x2, hg);
+#if GM_EPI_DIAG == 1          // timing only: no GELU
+                const unsigned pr = gm_pack2((float)bg[0] * (float)bv[0], (float)bg[1] * (float)bv[1]);
+#else
                 const unsigned pr = gm_pack2(gm_gelu((float)bg[0]) * (float)bv[0], gm_gelu((float)bg[1]) * (float)bv[1]);
+#endif
                 const int so = __builtin_amdgcn_readfirstlane(corigin + (16 * mi + reg) * L.ldc2);
+#if GM_EPI_DIAG == 3          // timing only: h as ONE 8-byte store per lane (val / gate pairs interleaved inside the tile's 256 columns)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{hv, hg}, rsC, L.voffC, so, GM_STORE_AUX);
+#else
                 __builtin_amdgcn_raw_buffer_store_b32(hv, rsC, L.voffC, so, GM_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b32(hg, rsC, L.voffC, so + L.gate_off, GM_STORE_AUX);
+#endif
+#if GM_EPI_DIAG == 2          // timing only: the product is computed and kept live, its store dropped by a record count of 0
+                __builtin_amdgcn_raw_buffer_store_b32(pr, gm_rsrc(L.G, 0), L.voffG, __builtin_amdgcn_readfirstlane(gorigin + (16 * mi + reg) * L.ldg2), GM_STORE_AUX);
+#else
                 __builtin_amdgcn_raw_buffer_store_b32(pr, rsG, L.voffG, __builtin_amdgcn_readfirstlane(gorigin + (16 * mi + reg) * L.ldg2), GM_STORE_AUX);
+#endif
             }
         }
     }
@@ -224,7 +240,7 @@ template <int EPI, int KIND>
 __device__ __forceinline__ void ktile(const Lane& L, const Ctx& c1, int kt1, const Ctx& c2, int kt2, int b, int wave, Frags& f, f32x4 (&acc)[8][4],
                                       const Out& prev, const Out& cur) {
     constexpr bool FIRST = KIND == 1, LAST = KIND == 3;
-    constexpr int SPP = EPI == 0 ? 8 : 24;
+    constexpr int SPP = EPI == 0 ? 8 : (GM_EPI_DIAG == 3 ? 16 : 24);
     load_frags<0>(L, b, f);
     stageW(L, c1, kt1, b ^ 1, 1, wave);
     if (FIRST) store_half<EPI, 1, 0>(acc, L, prev);
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
         const int ra = (128 * wr + j) * 128 + 16 * (g ^ (j & 7));
         const int rw = 32768 + (64 * wc + j) * 128 + 16 * (g ^ (j & 7));
         L.rdA[0] = ra; L.rdA[1] = ra ^ 64; L.rdW[0] = rw; L.rdW[1] = rw ^ 64;
-        L.voffC = 4 * g * L.ldc2 + (EPI == 0 ? 8 : 4) * j;
+        L.voffC = 4 * g * L.ldc2 + (EPI == 0 || GM_EPI_DIAG == 3 ? 8 : 4) * j;
         L.voffG = 4 * g * L.ldg2 + 4 * j;
     }
     // this wave's pieces cover LDS rows 8 wave .. + 7 of a 64-row group = MFMA columns 8 (wave & 1) .. + 7 of n-tile wave >> 1
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     auto out_of = [&](TileXY t) {
         Out o;
         o.nC = szC; o.nG = szG;
-        o.c = (t.tm * 256 + 128 * wr) * L.ldc2 + (t.tn * (EPI == 0 ? 256 : 128) + (EPI == 0 ? 64 : 32) * wc) * 2;
+        o.c = (t.tm * 256 + 128 * wr) * L.ldc2 + (t.tn * (EPI == 0 || GM_EPI_DIAG == 3 ? 256 : 128) + (EPI == 0 || GM_EPI_DIAG == 3 ? 64 : 32) * wc) * 2;
         o.g = EPI == 0 ? 0 : (t.tm * 256 + 128 * wr) * L.ldg2 + (t.tn * 128 + 32 * wc) * 2;
         return o;
     };
