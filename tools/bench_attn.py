@@ -17,6 +17,8 @@ ap.add_argument("--variants", default="0", help="0: product kernels (dh 64 forwa
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")
+ap.add_argument("--dirichlet", type=int, default=None, metavar="SEED", help="per-sample splits of N = sum(--split) kept tokens drawn from "
+                "Dirichlet(1) like the pretraining masks (samples then differ in work: what the bench step runs), instead of --split for every sample")
 ap.add_argument("--lib", default=None, help="another build of libmmae_hip.so (A/B runs inside one gpurun call)")
 ap.add_argument("--pair", action="store_true", help="variant 0 = the dQ + dK/dV kernel PAIR (ops.MHA_FUSED_BWD = False) instead of the fused "
                 "backward the product path runs; variant 50 is the fused kernel either way")
@@ -30,18 +32,37 @@ B, H, dh, P = a.B, a.H, a.dh, 256
 nm = [int(x) for x in a.split.split(",")]
 N = sum(nm); S = N + P; I = H * dh
 lens = torch.tensor([nm + [P]] * B, dtype=torch.int32)
+if a.dirichlet is not None:
+    gen = torch.Generator().manual_seed(a.dirichlet)
+    pr = torch._sample_dirichlet(torch.ones(B, len(nm), dtype=torch.float64), generator=gen)
+    # generate_random_masks (MM/multimae_crossattn.py:183-235): round(share * N) kept per modality, at most the P patches it has; the first N of
+    # "kept tokens in random order, then masked tokens in random order" are encoded, so a shortfall is filled uniformly from the masked ones
+    cnt = torch.clamp(torch.round(pr * N), max=P).to(torch.int64)
+    for b in range(B):
+        while int(cnt[b].sum()) > N:
+            cnt[b, int(cnt[b].argmax())] -= 1
+        short = N - int(cnt[b].sum())
+        if short > 0:
+            pool = torch.repeat_interleave(torch.arange(len(nm)), P - cnt[b])
+            pick = pool[torch.randperm(len(pool), generator=gen)[:short]]
+            cnt[b] += torch.bincount(pick, minlength=len(nm))
+    lens[:, :len(nm)] = cnt.to(torch.int32)
 st = torch.zeros_like(lens)
 for b in range(B):
     off = 0
     for s_ in range(len(nm)):
-        st[b, s_] = b * N + off; off += nm[s_]
+        st[b, s_] = b * N + off; off += int(lens[b, s_])
     st[b, len(nm)] = B * N + b * P
 seg = ops.Segments(st.to(dev), lens.to(dev), S)
 torch.manual_seed(0)
 qkv = torch.randn(B * S, 3 * I, device=dev).to(torch.bfloat16).requires_grad_()
 g = torch.randn(B * S, I, device=dev).to(torch.bfloat16)
-pairs = sum(n * n for n in nm) + P * S
+per_sample = (lens[:, :len(nm)].long() ** 2).sum(1) + P * S
+pairs = float(per_sample.double().mean())
 flops_fwd = 4.0 * dh * H * pairs * B
+if a.dirichlet is not None:
+    print("score cells per sample: mean %.0f  max %.0f (%.2fx)  min %.0f" % (pairs, float(per_sample.max()), float(per_sample.max()) / pairs,
+                                                                        float(per_sample.min())), flush=True)
 lib = _lib.lib()
 has_var = True
 
