@@ -67,6 +67,9 @@ class GradAllReducer:
         self.engine = engine
         self.static_unused = bool(static_unused)
         self.grad_dtype = grad_dtype
+        # a process group of ONE rank (init_distributed under MMAE_DIST_SINGLE_RANK=1: the one-GPU rehearsal of the RCCL path) still
+        # issues every collective; without a process group there is nothing to issue them on
+        self.collective = dist.is_initialized()
         self.stats = {"allreduce_bytes": 0, "buckets": 0, "comm_exposed_ms": 0.0}
         self._next = 0
         if engine is not None:
@@ -142,9 +145,13 @@ class GradAllReducer:
             self.engine.flush()                              # batched copy of the small gradients into the flat buffer
         self._sent_bytes += b.flat.numel() * torch.empty((), dtype=self.grad_dtype).element_size()
         self._sent_buckets += 1
-        if self.world > 1:
-            # RCCL averages inside the collective (ncclAvg); gloo has no AVG, finish() scales there
-            self._avg_in_op = self.average and dist.get_backend(self.group) == "nccl"
+        if self.collective:
+            # RCCL averages inside the collective (ncclAvg); gloo has no AVG, finish() scales there.  Not inside a graph capture: SUM is
+            # the collective every graph user runs; RCCL's one-rank ncclAvg (a pre-multiply kernel) replayed with a stale scalar on this
+            # stack (round 5: losses and weights off from the second replay on, SUM or no collective bitwise), so a captured step sums
+            # and finish() scales.  (Exact either way for a power-of-two world.)
+            self._avg_in_op = self.average and self.world > 1 and dist.get_backend(self.group) == "nccl" and \
+                not (b.flat.is_cuda and torch.cuda.is_current_stream_capturing())
             buf = b.flat
             if self.grad_dtype != torch.float32:
                 b.wire = b.flat.to(self.grad_dtype)
@@ -194,6 +201,11 @@ class GradAllReducer:
         """Send what backward could not complete (buckets holding parameters without a gradient), in order; wait for every
         transfer on the current stream; average.  With static_unused=False also agree on the set of parameters that got a
         gradient on ANY rank and hand those their (averaged) gradient on every rank."""
+        capturing = bool(self.buckets) and self.buckets[0].flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            ok, why = self.capturable()
+            if not ok:
+                raise RuntimeError("GradAllReducer.finish() inside a graph capture: " + why)
         if self.engine is not None:
             self.engine.flush()
         for b in self.buckets[self._next:]:
@@ -227,11 +239,11 @@ class GradAllReducer:
                                  device=self.buckets[0].flat.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             used = flags.tolist()                            # host sync, like DDP's local_used_map copy
-        on_gpu = self.buckets and self.buckets[0].flat.is_cuda
+        on_gpu = self.buckets and self.buckets[0].flat.is_cuda and not capturing     # (timing events cannot be read back from a graph)
         if on_gpu:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        else:
+        elif not capturing:
             import time
             t0 = time.perf_counter()
         for b in self.buckets:
@@ -239,7 +251,7 @@ class GradAllReducer:
                 b.work.wait()
         if on_gpu:
             ev1.record()
-        else:
+        elif not capturing:
             self.stats["comm_exposed_ms"] = (time.perf_counter() - t0) * 1e3
         for b in self.buckets:
             if b.wire is not None:
@@ -263,6 +275,18 @@ class GradAllReducer:
                     bi, off = self._where[p]
                     p.grad = self.buckets[bi].flat[off:off + p.numel()].view_as(p)
         self._first = False
+
+    def capturable(self):
+        """-> (ok, reason).  A step with this reducer can be captured into a hipGraph (pretrain.PretrainStep.capture) once nothing in
+        finish() needs the host: the static unused set is agreed (one eager step has run) and stays static.  The collectives themselves
+        are captured as graph nodes on RCCL's stream; the bucket bookkeeping runs once, at capture, and the replays repeat its launches."""
+        if not self.static_unused:
+            return False, "static_unused=False agrees on the used parameters through the host every step"
+        if self._first:
+            return False, "run one eager step first (the unused-parameter set is agreed on it)"
+        if self.collective and dist.get_backend(self.group) != "nccl":
+            return False, "only RCCL collectives can be captured (backend %s)" % dist.get_backend(self.group)
+        return True, ""
 
     def exposed_ms(self) -> float:
         """Time the compute stream waited for the collectives in the last finish() (host sync on the GPU path)."""

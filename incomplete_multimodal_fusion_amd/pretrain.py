@@ -284,13 +284,15 @@ class PretrainStep:
         one (GPU-bound).
         The `warmup` steps that precede the capture are REAL training steps on `tasks_dict` (optimizer updates at the learning
         rate of the moment, step counts advanced): a schedule that starts after capture() starts at step `warmup`.  A step can be
-        captured once; a failed capture leaves the step eager and unchanged.  One process / one GPU, the flat engine, fixed shapes; new batches are COPIED into the captured input
+        captured once; a failed capture leaves the step eager and unchanged.  The flat engine, fixed shapes; with a gradient reducer
+        (dp.GradAllReducer over the engine's flat buffer, static unused set, RCCL) its bucket all-reduces are captured as graph nodes on
+        RCCL's stream -- every rank captures and replays in lockstep; new batches are COPIED into the captured input
         tensors (`tasks_dict`'s, kept here) before a replay.  The host-side part of the mask draw (the Dirichlet shares) stays on
         the host: replay() draws and copies them into a static device tensor first.  Eager calls must not be mixed in after
         capture (the optimizer's device-side replay count would fall out of step with the host's count)."""
         from .engine import FlatAdamW
-        if not isinstance(self.opt, FlatAdamW) or self.reducer is not None or self.balancer_opt is not None:
-            raise NotImplementedError("capture(): the flat engine, one rank, no companion optimizer")
+        if not isinstance(self.opt, FlatAdamW) or self.balancer_opt is not None:
+            raise NotImplementedError("capture(): the flat engine, no companion optimizer")
         if ops._TIMER is not None or ops._TIMERS or getattr(self.model, "layer_timer", None) is not None:
             raise RuntimeError("capture(): switch the bench timers off first (HIP-event brackets cannot be captured)")
         if getattr(self, "_graph", None) is not None:
@@ -310,6 +312,16 @@ class PretrainStep:
                 self(tasks_dict, task_masks)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if self.reducer is not None:
+            ok, why = self.reducer.capturable()             # (after the warm-up steps: the first one agrees the unused-parameter set)
+            if not ok:
+                raise NotImplementedError("capture(): the gradient reducer cannot be captured -- " + why)
+            if self.reducer.collective:
+                # the process group's watchdog thread polls the events of the warm-up steps' collectives until it has seen each one
+                # complete (they all have: synchronize above); an event query while this thread captures aborts the process on this
+                # stack, so give its polling loop (100 ms period) time to drop them -- collectives issued during capture are not polled
+                import time
+                time.sleep(0.5)
         if tuning:
             tun.tuning_enable(False)                         # an unseen shape must not start timing runs inside the capture
         self.model.mask_draws = self._draws
@@ -319,7 +331,9 @@ class PretrainStep:
         check = getattr(self.model, "check_masks", False)
         self.model.check_masks = False                       # a host-side check of explicit masks: the warm-up steps ran it
         try:
-            with torch.cuda.graph(graph):
+            # with a reducer: thread-local capture mode -- the process group's watchdog thread polls events of earlier collectives,
+            # which the global mode forbids to EVERY thread while one captures
+            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if self.reducer is not None else {})):
                 self._static_out = self(tasks_dict, task_masks)
         except BaseException:
             # the step stays eager: back to fresh mask draws per call (not the one static share), nothing captured

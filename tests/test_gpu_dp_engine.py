@@ -110,3 +110,27 @@ def test_bench_step_over_rccl_single_rank_matches_the_undistributed_step():
     b = json.loads([l for l in ranked.stdout.splitlines() if l.startswith("{")][-1])
     assert a["backend"] == "none" and b["backend"] == "nccl" and b["ranks"] == 1 and b["n_gpus"] == 1
     assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"]), (a["config"]["loss"], b["config"]["loss"])
+
+
+def test_captured_step_with_the_rccl_reducer_replays_like_eager():
+    """PretrainStep.capture with a GradAllReducer: the bucket all-reduces become graph nodes on RCCL's stream (one rank on this box's one
+    GPU, every collective really issued: tests/dp_capture_worker.py).  The replays must repeat the eager steps bit for bit."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), MMAE_DIST_SINGLE_RANK="1")
+    env.pop("MMAE_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_capture_worker.py")], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert not d["capturable_before_first_step"] and "eager step" in d["why"]
+    assert d["sent_buckets"] == d["buckets"] > 2
+    assert d["losses_replay"] == d["losses_eager"], d
+    assert d["master_equal"] and d["exp_avg_equal"] and d["steps"] == [6, 6]
