@@ -530,7 +530,7 @@ extern "C" int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int n
     d.scale = scale; d.empty_mode = empty_mode;
     if (variant > 0) { d.hpb_req = (variant >> 8) & 15; variant &= 255; }
     const int mq = max_q_rows / 64 + nseg, mk = max_k_rows / 64 + nseg;
-    if (variant >= 50 && variant <= 54) {          // fused backward (mha_sh_bwd_kernel): the workspace continues behind the three planes -- mmae_mha_bwd_fused_ws_floats
+    if (variant >= 50 && variant <= 55) {          // fused backward (mha_sh_bwd_kernel): the workspace continues behind the three planes -- mmae_mha_bwd_fused_ws_floats
         d.dq_ws = delta_ws + 3L * H * q_rows_total;
         d.max_qt = mq;
     }

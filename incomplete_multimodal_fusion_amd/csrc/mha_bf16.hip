@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void mha_bf16_fwd32_kernel(MhaDesc p) {
 // ------------------------------------------------------------------------------------------------------ host side
 // `variant` (per call; mmae_internal.h): forward tiling 0 default, 1, 8; backward 2 -- tools/bench_attn.py A/B material.
 int mha_bf16_fwd(const MhaDesc& d, int head_dim, int g_variant, hipStream_t st) {
-    if (g_variant == 23 || (g_variant >= 50 && g_variant <= 54)) g_variant = 0;   // backward-only variants (head-looping dQ, fused backward): default forward
+    if (g_variant == 23 || (g_variant >= 50 && g_variant <= 55)) g_variant = 0;   // backward-only variants (head-looping dQ, fused backward): default forward
     if (d.max_tiles > MAXT) return MMAE_ERR_ARG;
     if (head_dim == 64 && g_variant >= 30 && g_variant <= 32) return mha_sh_fwd(d, g_variant - 20, st);   // two tiles per barrier (+ its diagnostics)
     if (head_dim == 64 && g_variant == 35) return mha_sh_fwd(d, 10, st);
@@ -1146,7 +1146,7 @@ int mha_bf16_bwd(MhaDesc d, int head_dim, int max_q_tiles, int max_k_tiles, int 
     if ((g_variant >= 30 && g_variant <= 32) || g_variant == 40 || g_variant == 41 || g_variant == 45) g_variant = 0;   // forward-only variants: default backward
     if (g_variant == 35) g_variant = 5;                      // two-tile forward + sample-head dQ
     d.max_tiles = max_q_tiles;
-    if (g_variant >= 50 && g_variant <= 54) {                // dQ + dK + dV in ONE key-stationary kernel (mha_sh.hip: mha_sh_bwd_kernel); 51..53: its diagnostics
+    if (g_variant >= 50 && g_variant <= 55) {                // dQ + dK + dV in ONE key-stationary kernel (mha_sh.hip: mha_sh_bwd_kernel); 51..55: its diagnostics
         if (head_dim == 64 && mha_sh_fused_supported(d)) return mha_sh_bwd_fused(d, g_variant - 50, st);
         g_variant = 0;                                       // shapes beyond its schedule tables: the product pair
     }

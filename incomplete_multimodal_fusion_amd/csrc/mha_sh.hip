@@ -128,6 +128,33 @@ __device__ __forceinline__ void sh_dma4(const float* base, int n, float* lds, in
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)lds, 4, (lane + z) * 4, 0, 0, 0);
 }
 
+// Plain buffer loads as inline assembly: the results arrive asynchronously and are waited for with the kernel's own counted
+// s_waitcnt (sh_wait_vm + sh_pin) -- a load the compiler tracks would get ITS wait, which on a loader wave covers the ring DMA issued
+// after it (the compiler merges the waves' different instruction streams to the strictest count).  Entries beyond `bytes` read as 0.
+// (s_nop 4: the descriptor's SGPRs may come straight from v_readfirstlane -- five wait states before a VMEM instruction reads them, which
+// the compiler's hazard recognizer provides for its own instructions but not inside an asm statement.)
+__device__ __forceinline__ u32x4 sh_rsrc_words(const void* base, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu,
+                 (unsigned)sh_uni(bytes), 0x00020000u};
+}
+__device__ __forceinline__ u32x4 sh_ld128_async(const void* base, int bytes, int voff) {
+    u32x4 v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(sh_rsrc_words(base, bytes)) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned sh_ld32_async(const void* base, int bytes, int voff) {
+    unsigned v;
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(sh_rsrc_words(base, bytes)) : "memory");
+    return v;
+}
+// after sh_wait_vm: no use of the loaded registers may be scheduled above the wait
+__device__ __forceinline__ void sh_pin(u32x4& a, u32x4& b, unsigned& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+template <int CTRL>
+__device__ __forceinline__ float sh_add_dpp(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
 // transposed operand of the 32x32x16 products: element j of lane (r = lane & 31, hh = lane >> 5) is
 // X[base + 8 (j >> 2) + 4 hh + (j & 3)][32 dhb + r] of the swizzled image (mha_bf16.hip: tr32_frag)
 __device__ __forceinline__ bf16x8 sh_tr(const bf16* img, int off0, int off1) {
@@ -1178,7 +1205,11 @@ __global__ __launch_bounds__(256) void mha_rowconst_kernel(MhaDesc p) {
 
 // MODE (diagnostic builds, never the product path; wrong dQ): 1 = no dS exchange and no dQ phase (the dK / dV part alone on eight waves),
 // 2 = dQ phase without the workspace traffic of the partials
-template <int MODE>
+// RC (variant 55, not the product): the row constants of a tile (-lse log2 e, -delta = -rowsum(dO o O)) are formed HERE, one step ahead,
+// by the four loader waves while waves 0..3 run the dQ products, and written into the ring stage of the next step, instead of being read
+// from the planes of the pre-pass mha_rowconst_kernel.  Saves the pre-pass (62 us) and costs the kernel 35 (255 VGPRs instead of 232, the
+// loader waves reach the barrier later): -25 us per call in isolation, nothing measurable in the step.
+template <int MODE, bool RC = false>
 __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hpb) {
     __shared__ __attribute__((aligned(1024))) bf16 ringQ[SB_NS][4096];
     __shared__ __attribute__((aligned(1024))) bf16 ringO[SB_NS][4096];
@@ -1319,15 +1350,56 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
                 sh_dma(qb_, n, qsb, qv ^ (16 * (pc & 1)), 8 * pc * qsb, &ringQ[lstage][pc * 512]);
                 sh_dma(ob_, n, dosb, ov ^ (16 * (pc & 1)), 8 * pc * dosb, &ringO[lstage][pc * 512]);
             }
-            const float* lp = p.delta + ((long)p.H + h) * p.stat_stride + row0;
-            const float* dp = p.delta + (2L * p.H + h) * p.stat_stride + row0;
-            sh_dma4(lp, n, &ringL[lstage][0], lane);
-            sh_dma4(dp, n, &ringL[lstage][64], lane);
-            vm += 18; myseq = vm;
+            if (!RC) {
+                const float* lp = p.delta + ((long)p.H + h) * p.stat_stride + row0;
+                const float* dp = p.delta + (2L * p.H + h) * p.stat_stride + row0;
+                sh_dma4(lp, n, &ringL[lstage][0], lane);
+                sh_dma4(dp, n, &ringL[lstage][64], lane);
+            }
+            vm += RC ? 16 : 18; myseq = vm;
         }
         ++lj;
         if (++lstage == SB_NS) lstage = 0;
         if (++li == nsteps) { li = 0; ++lh; }
+    };
+    // row constants of step i of head index hx (RC), formed by waves 4..7 -- the loaders, which sit out the dQ phase: a lane holds one
+    // 32-byte piece of a row of O and of dO (four lanes per row, 16 rows per wave) and the row's lse from rc_issue to rc_finish one step
+    // later, both after the step's second barrier, while waves 0..3 run the dQ products
+    u32x4 rc_o[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, rc_d[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned rc_l = 0u;
+    int rcseq = 0;
+    const bool rc_wave = RC && wave >= 4;
+    const int rc_row = 16 * (wave & 3) + (lane >> 2), rc_c = lane & 3;
+    auto rc_issue = [&](int i, int hx) {
+        const long row0 = s_row(i); const int n = s_info(i) & 255, h = h0 + hx;
+        const int osb = (int)p.o_stride * 2;
+        const bf16* ob = reinterpret_cast<const bf16*>(p.o) + row0 * p.o_stride + h * 64;
+        const bf16* db = dog + row0 * p.do_stride + h * 64;
+        rc_o[0] = sh_ld128_async(ob, n * osb, rc_row * osb + 32 * rc_c);
+        rc_o[1] = sh_ld128_async(ob, n * osb, rc_row * osb + 32 * rc_c + 16);
+        rc_d[0] = sh_ld128_async(db, n * dosb, rc_row * dosb + 32 * rc_c);
+        rc_d[1] = sh_ld128_async(db, n * dosb, rc_row * dosb + 32 * rc_c + 16);
+        rc_l = sh_ld32_async(p.lse + (long)h * p.stat_stride + row0, n * 4, rc_row * 4);
+        vm += 5; rcseq = vm;
+    };
+    auto rc_finish = [&](int to_stage) {
+        sh_wait_vm(vm - rcseq);
+        sh_pin(rc_o[0], rc_d[0], rc_l);
+        sh_pin(rc_o[1], rc_d[1], rc_l);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, rc_o[k]), d8 = __builtin_bit_cast(bf16x8, rc_d[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)d8[j];
+        }
+        acc = sh_add_dpp<0xB1>(acc);                              // lanes ^ 1, ^ 2 of the quad
+        acc = sh_add_dpp<0x4E>(acc);
+        if (rc_c == 0) {
+            ringL[to_stage][rc_row] = -__builtin_bit_cast(float, rc_l) * SH_LOG2E;
+            ringL[to_stage][64 + rc_row] = -acc;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // in LDS before this wave reaches the next step's barrier
     };
     auto kb_of = [&](int ps) { return SB_W * ps + wave; };
     // next pass's key block: K rows -> kimg[buf][wave] (LDS-DMA), V rows -> registers in the operand layout (rows >= n read as zero)
@@ -1362,9 +1434,13 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
     // ---- prologue
     int nxt_ps = 0, nxt_h = 0, cur_buf = 0, nxt_buf = 0;
     bool nxt_valid = kb_of(0) < NB;
+    int rci = 0, rch = 0;                                          // the step whose constants are fetched next
+    auto rc_issue_next = [&]() { rc_issue(rci, rch); if (++rci == nsteps) { rci = 0; ++rch; } };
+    if (rc_wave) rc_issue_next();
     if (nxt_valid) issue_kv(0, h0, 0);
     mark = vm;
     for (int i = 0; i < SB_D && i < G; ++i) issue_ring();
+    if (rc_wave) { rc_finish(0); if (G > 1) rc_issue_next(); }     // step 0's constants: published by the first barrier below
 
     int si = 0, hi = 0, stage = 0, cur_ps = -1;
     for (int g = 0; g < G; ++g) {
@@ -1518,6 +1594,10 @@ __global__ __launch_bounds__(SB_W * 64) void mha_sh_bwd_kernel(MhaDesc p, int hp
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        if (rc_wave && g + 1 < G) {
+            rc_finish(stage + 1 == SB_NS ? 0 : stage + 1);         // the next step's stage: its readers finished two barriers ago
+            if (g + 2 < G) rc_issue_next();                         // a whole step in flight
+        }
         if (dq_wave) {
             const bf16* Kc = &kimg[cur_buf][0][0];
             const int ka = ad.tr00 ^ (32 * dq_d), kb2 = ad.tr00 ^ (32 * dq_d + 520), sa = ad.tr00 ^ (32 * dq_q), sb2 = ad.tr00 ^ (32 * dq_q + 520);
@@ -1635,17 +1715,20 @@ bool mha_sh_fused_supported(const MhaDesc& d) {
 
 int mha_sh_bwd_fused(const MhaDesc& d, int mode, hipStream_t st) {
     if (!mha_sh_fused_supported(d)) return MMAE_ERR_ARG;
-    const long n = d.stat_stride * d.H;
-    if (mode != 3) {
+    // mode 0: product (row constants from the pre-pass mha_rowconst_kernel); 1 / 2 / 4: its diagnostic builds; 3: without the pre-pass (stale
+    // planes, timing only); 5: row constants formed inside the kernel by the loader waves (RC; correct results: isolated -25 us per call at
+    // the bench shape, +-0 in the step -- DESIGN.md section 4)
+    if (mode != 3 && mode != 5) {
         MMAE_LAUNCH(mha_rowconst_kernel, dim3((unsigned)((d.stat_stride + 31) / 32)), dim3(256), 0, st, d);
         MMAE_CHECK_LAUNCH();
     }
     const int hpb = sh_heads_per_block(d.B, d.H, d.hpb_req);
     const dim3 grid(d.B * (d.H / hpb)), blk(SB_W * 64);
-    if (mode == 1) MMAE_LAUNCH(mha_sh_bwd_kernel<1>, grid, blk, 0, st, d, hpb);
-    else if (mode == 2) MMAE_LAUNCH(mha_sh_bwd_kernel<2>, grid, blk, 0, st, d, hpb);
-    else if (mode == 4) MMAE_LAUNCH(mha_sh_bwd_kernel<4>, grid, blk, 0, st, d, hpb);
-    else MMAE_LAUNCH(mha_sh_bwd_kernel<0>, grid, blk, 0, st, d, hpb);          // (mode 3: without the row-constant pre-pass -- stale planes, timing only)
+    if (mode == 1) MMAE_LAUNCH((mha_sh_bwd_kernel<1, false>), grid, blk, 0, st, d, hpb);
+    else if (mode == 2) MMAE_LAUNCH((mha_sh_bwd_kernel<2, false>), grid, blk, 0, st, d, hpb);
+    else if (mode == 4) MMAE_LAUNCH((mha_sh_bwd_kernel<4, false>), grid, blk, 0, st, d, hpb);
+    else if (mode == 5) MMAE_LAUNCH((mha_sh_bwd_kernel<0, true>), grid, blk, 0, st, d, hpb);
+    else MMAE_LAUNCH((mha_sh_bwd_kernel<0, false>), grid, blk, 0, st, d, hpb);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }

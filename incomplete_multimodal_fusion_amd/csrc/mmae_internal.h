@@ -24,8 +24,9 @@ int mmae_mha_bwd_variant(int dtype, int head_dim, int B, int H, int nseg, const 
                          long dk_stride, long dv_stride, long q_rows_total, const int* q_seg_start, const int* q_seg_len,
                          const int* k_seg_start, const int* k_seg_len, int max_q_rows, int max_k_rows, float scale,
                          int empty_mode, int variant, void* stream);
-/* backward variants 50..54: the fused dQ + dK + dV kernel (product entry: mmae_mha_bwd_fused) and its diagnostic builds -- 51 no dQ part,
+/* backward variants 50..55: the fused dQ + dK + dV kernel (product entry: mmae_mha_bwd_fused) and its diagnostic builds -- 51 no dQ part,
  * 52 no partial-tile workspace traffic, 53 no row-constant pre-pass, 54 dS exchange without the dQ products (51..54: wrong dQ, timing only);
+ * 55 the row constants formed inside the kernel instead of by the pre-pass (correct results; an experiment that did not pay in the step);
  * delta_ws sized by mmae_mha_bwd_fused_ws_floats (include/mmae_hip.h). */
 /* diagnostic (variant 9 of the forward): copies the 8 per-launch stamp sums to host8 and clears them (host sync). */
 int mmae_debug_mha_stamps(unsigned long long* host8);

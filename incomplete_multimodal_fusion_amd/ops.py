@@ -745,7 +745,7 @@ class _MHA(torch.autograd.Function):
         fused = (not variant and MHA_FUSED_BWD and qt.dtype == torch.bfloat16 and dh == 64 and qseg.max_rows >= 128 and kseg.max_rows >= 128 and
                  (kseg.max_rows // 32 + kseg.nseg + 7) // 8 <= MHA_FUSED_MAX_PASSES and
                  bool(lib_.mmae_mha_bwd_fused_supported(dt(qt), dh, qseg.B, H, qseg.nseg, qseg.max_rows, kseg.max_rows)))
-        if fused or (variant > 0 and 50 <= (variant & 255) <= 54):      # planes + fp32 partial dQ tiles
+        if fused or (variant > 0 and 50 <= (variant & 255) <= 55):      # planes + fp32 partial dQ tiles
             nws = lib_.mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
         else:
             nws = lib_.mmae_mha_bwd_ws_floats(H, lse.shape[1])

@@ -314,7 +314,8 @@ HPB_CASES = [(torch.bfloat16, 64, v, 8, hpb) for v in (0, 5, 50) for hpb in (1, 
 
 @pytest.mark.parametrize("T,dh,variant,H,hpb", [(torch.float32, 64, 0, 3, 0), (torch.float32, 32, 0, 3, 0), (torch.bfloat16, 64, 0, 3, 0),
                                                 (torch.bfloat16, 32, 0, 3, 0), (torch.bfloat16, 64, 2, 3, 0), (torch.bfloat16, 64, 4, 3, 0),
-                                                (torch.bfloat16, 64, 5, 3, 0), (torch.bfloat16, 64, 23, 3, 0), (torch.bfloat16, 64, 50, 3, 0)] + HPB_CASES)
+                                                (torch.bfloat16, 64, 5, 3, 0), (torch.bfloat16, 64, 23, 3, 0), (torch.bfloat16, 64, 50, 3, 0),
+                                                (torch.bfloat16, 64, 55, 3, 0)] + HPB_CASES)     # 55: the fused backward forming its row constants itself
 @pytest.mark.parametrize("empty_mode", [0, 1])
 def test_mha_kernel_ragged_segments(T, dh, empty_mode, variant, H, hpb):
     from incomplete_multimodal_fusion_amd import ops
@@ -674,7 +675,7 @@ def test_mha_bf16_fast_path_matches_generic_kernels(dh):
     res = []
     # -1: generic dtype-templated kernels (csrc/mmae_internal.h), 0: bf16 fast path (dh 64: 32x32x16 forward), 2: the round-1
     # 16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ (the stamped diagnostic builds 8 / 9 exist in `make DIAG=1` only)
-    for variant in ((-1, 0, 2, 4, 5, 50) if dh == 64 else (-1, 0)):
+    for variant in ((-1, 0, 2, 4, 5, 50, 55) if dh == 64 else (-1, 0)):
         x = qkv.clone().requires_grad_()
         out = ops.mha_self(x, H, dh, seg, dh ** -0.5, variant=variant)
         out.backward(g)

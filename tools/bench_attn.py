@@ -13,7 +13,7 @@ ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--H", type=int, default=8)
 ap.add_argument("--dh", type=int, default=64)
 ap.add_argument("--variants", default="0", help="0: product kernels (dh 64 forward = 32x32x16, backward = the fused dQ + dK + dV kernel), 2: round-1 "
-                "16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ + dK/dV pair, 50: fused backward, 51-54: its diagnostics")
+                "16x16x32 forward, 4: 256-query tiles, 5: sample-head dQ + dK/dV pair, 50: fused backward, 51-54: its diagnostics, 55: row constants formed in the kernel (no pre-pass)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", default="128,128,128", help="kept tokens per modality (N = sum), P = 256 fusion tokens")
