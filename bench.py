@@ -330,7 +330,7 @@ def dry_main(args):
         dist.all_gather(allv, mine)
         per_rank = [1e3 * float(v) / args.steps for v in allv]
         diag = {"dp": {"ranks_reported_by_backend": dist.get_world_size(), "allreduce_bytes_per_step": red.stats["allreduce_bytes"],
-                       "buckets_per_step": red.stats["buckets"], "grad_wire_dtype": args.grad_dtype,
+                       "buckets_per_step": red.stats["buckets"], "grad_wire_dtype": args.grad_dtype, "captured": False,
                        "comm_exposed_ms_last_step_max_over_ranks": round(float(ex.item()), 3),
                        "rank_ms_per_step_min": round(min(per_rank), 3), "rank_ms_per_step_max": round(max(per_rank), 3)}}
     if rank == 0:
@@ -395,6 +395,7 @@ def dp_diagnostics(reducer, world, steps, ranks_dt, device, distributed):
     return {"dp": {"ranks_reported_by_backend": dist.get_world_size() if distributed else 1,
                    "allreduce_bytes_per_step": reducer.stats["allreduce_bytes"], "buckets_per_step": reducer.stats["buckets"],
                    "grad_wire_dtype": "bf16" if reducer.grad_dtype == torch.bfloat16 else "fp32",
+                   "captured": False,        # the N > 1 region is eager by design: the captured-DP step is an opt-in, experimental leg
                    "comm_exposed_ms_last_step_max_over_ranks": round(float(exposed.item()), 3),
                    "rank_ms_per_step_min": round(min(per_rank), 3), "rank_ms_per_step_max": round(max(per_rank), 3)}}
 

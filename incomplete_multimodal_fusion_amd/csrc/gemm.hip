@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned gm_pack2(float lo, float hi) {          // o
 }
 // GELU of the FF1 + GEGLU epilogue (exact-erf GELU of the reference: F.gelu, DSI-MM/zorro_utils.py:115-118).  The epilogue is VALU-issue
 // bound, so the form with the fewest instructions that is still exact at the precision the result is stored in:
-//   GM_GELU_FAST 1 (default): x * sigma(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax on |x| <= 9, argument clamped there) to
+//   GM_GELU_FAST 1 (default): x * sigma(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax on |x| <= 9, x^2 clamped there) to
 //     |gelu - x Phi(x)| <= 2.6e-5 for EVERY bf16 input: the product g = gelu(gate) * val is rounded to bf16 (relative 2^-9) right after, and
 //     the bf16-rounded gelu differs from the exact one's for 18 of the 2130 bf16 inputs with |gelu| > 0.02, by one ulp (tools/probes/
 //     gelu_form_check.py).  8 instructions (10 issue slots with the two 8-cycle transcendentals) against 13 (15).
@@ -55,11 +55,13 @@ __device__ __forceinline__ unsigned gm_pack2(float lo, float hi) {          // o
 #endif
 __device__ __forceinline__ float gm_gelu(float x) {
 #if GM_GELU_FAST
-    const float xc = __builtin_amdgcn_fmed3f(x, -9.f, 9.f);
-    const float x2 = xc * xc;
+    // the polynomial is clamped through its argument x^2 (not x): beyond |x| = 9 the exponent x * p(81) keeps growing linearly, so the
+    // factor goes to exactly 1 (x -> +big: g == x) and exactly 0 (x -> -big: g == -0; with x itself clamped a gate of -1e30 came out
+    // as -2.3e18).  Same instruction count as the v_med3 form; identical results on |x| <= 9.
+    const float x2 = fminf(x * x, 81.f);
     // -log2(e) * {1.59501577, 7.40112920e-2, -7.03033577e-4}
     const float p = fmaf(fmaf(1.01426305e-3f, x2, -1.06775723e-1f), x2, -2.30112136f);
-    const float e = __builtin_amdgcn_exp2f(xc * p);
+    const float e = __builtin_amdgcn_exp2f(x * p);
     return x * __builtin_amdgcn_rcpf(1.f + e);
 #else
     const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);

@@ -67,9 +67,12 @@ class GradAllReducer:
         self.engine = engine
         self.static_unused = bool(static_unused)
         self.grad_dtype = grad_dtype
-        # a process group of ONE rank (init_distributed under MMAE_DIST_SINGLE_RANK=1: the one-GPU rehearsal of the RCCL path) still
-        # issues every collective; without a process group there is nothing to issue them on
-        self.collective = dist.is_initialized()
+        # a process group of ONE rank issues its collectives only under MMAE_DIST_SINGLE_RANK=1 (the one-GPU rehearsal of the RCCL path:
+        # init_distributed); a single process that happens to run under a launcher keeps the plain path (no collectives, no wire-dtype
+        # rounding of the gradients); without a process group there is nothing to issue them on
+        self.collective = dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("MMAE_DIST_SINGLE_RANK") == "1")
+        self._issued = []                                    # Work handles of the collectives not yet known complete (quiesce())
+        self.captured = False                                # set by quiesce(): the following steps are graph replays
         self.stats = {"allreduce_bytes": 0, "buckets": 0, "comm_exposed_ms": 0.0}
         self._next = 0
         if engine is not None:
@@ -131,6 +134,8 @@ class GradAllReducer:
 
     # -- per step -----------------------------------------------------------------------------------------------------
     def prepare(self):
+        if len(self._issued) > 4 * max(len(self.buckets), 1):    # handles are only kept until they are known complete
+            self._issued = [w for w in self._issued if not w.is_completed()]
         self._seen = set()
         self._next = 0
         self._sent_bytes, self._sent_buckets = 0, 0
@@ -158,6 +163,8 @@ class GradAllReducer:
                 buf = b.wire
             b.work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg_in_op else dist.ReduceOp.SUM,
                                      group=self.group, async_op=True)
+            if not (buf.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._issued.append(b.work)
         else:
             b.work = True
 
@@ -279,7 +286,9 @@ class GradAllReducer:
     def capturable(self):
         """-> (ok, reason).  A step with this reducer can be captured into a hipGraph (pretrain.PretrainStep.capture) once nothing in
         finish() needs the host: the static unused set is agreed (one eager step has run) and stays static.  The collectives themselves
-        are captured as graph nodes on RCCL's stream; the bucket bookkeeping runs once, at capture, and the replays repeat its launches."""
+        are captured as graph nodes on RCCL's stream; the bucket bookkeeping runs once, at capture, and the replays repeat its launches.
+        Averaging: an eager step averages inside the collective (ncclAvg), a captured one sums and scales by 1 / world afterwards --
+        bitwise the same for a power-of-two world, one rounding apart otherwise."""
         if not self.static_unused:
             return False, "static_unused=False agrees on the used parameters through the host every step"
         if self._first:
@@ -288,8 +297,66 @@ class GradAllReducer:
             return False, "only RCCL collectives can be captured (backend %s)" % dist.get_backend(self.group)
         return True, ""
 
-    def exposed_ms(self) -> float:
-        """Time the compute stream waited for the collectives in the last finish() (host sync on the GPU path)."""
+    def quiesce(self, timeout_s: float = 60.0) -> dict:
+        """Deterministic hand-off before a hipGraph capture (pretrain.PretrainStep.capture): returns once every collective issued so far
+        is (1) complete on the device -- the kept Work handles are waited for and polled with is_completed() --, (2) issued and complete
+        on EVERY rank -- a barrier on the reducer's group, then a device synchronisation --, and (3) RETIRED by the process group's
+        watchdog thread, which polls the end events of outstanding collectives: c10d's flight recorder lists a collective as active
+        until the watchdog has seen it complete, so the wait ends when that list is empty.  Where the recorder is switched off
+        (TORCH_NCCL_TRACE_BUFFER_SIZE=0) step (3) falls back to three watchdog periods AFTER (1) and (2) have established completion.
+        Raises TimeoutError instead of capturing into a live poll.  -> {'handles', 'method', 'waited_s'} (method: none / gloo /
+        flight_recorder / watchdog_periods).  (capture() then sets `captured`: stats / exposed_ms() describe no replayed step.)"""
+        import time
+        t0 = time.monotonic()
+        info = {"handles": len(self._issued), "method": "none", "waited_s": 0.0}
+        if not self.collective:
+            return info
+
+        def expired():
+            return time.monotonic() - t0 > timeout_s
+        for w in self._issued:
+            w.wait()
+        while not all(w.is_completed() for w in self._issued):
+            if expired():
+                raise TimeoutError("GradAllReducer.quiesce(): collectives of the warm-up steps did not complete in %.0f s" % timeout_s)
+            time.sleep(0.001)
+        self._issued = []
+        dist.barrier(group=self.group)
+        if self.buckets and self.buckets[0].flat.is_cuda:
+            torch.cuda.synchronize(self.buckets[0].flat.device)
+        if dist.get_backend(self.group) != "nccl":
+            info["method"] = "gloo"
+        else:
+            c10d = torch._C._distributed_c10d
+            dump = getattr(c10d, "_dump_nccl_trace", None)
+
+            def entries(only_active):
+                import pickle
+                return len(pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=only_active)).get("entries", []))
+            recorder = False
+            try:
+                recorder = dump is not None and entries(False) > 0      # at least the barrier above is on record when it is on
+            except Exception:
+                recorder = False
+            if recorder:
+                info["method"] = "flight_recorder"
+                while entries(True) > 0:
+                    if expired():
+                        raise TimeoutError("GradAllReducer.quiesce(): the process group's watchdog has not retired %d completed "
+                                           "collectives after %.0f s" % (entries(True), timeout_s))
+                    time.sleep(0.005)
+            else:
+                info["method"] = "watchdog_periods"
+                time.sleep(0.3)                              # 3 x the watchdog's 100 ms pass, behind established completion
+        info["waited_s"] = round(time.monotonic() - t0, 4)
+        self.last_quiesce = info
+        return info
+
+    def exposed_ms(self) -> Optional[float]:
+        """Time the compute stream waited for the collectives in the last finish() (host sync on the GPU path).  None once the step
+        is captured (quiesce()): graph replays record no events and update no stats."""
+        if self.captured:
+            return None
         ev = getattr(self, "_pending_events", None)
         if ev is not None:
             ev[1].synchronize()

@@ -299,6 +299,19 @@ class FlatAdamW:
         for p in self._graph_params:
             self._pstep[id(p)] -= 1
 
+    def abort_capture(self):
+        """A capture that raised (pretrain.PretrainStep.capture's except path), possibly AFTER the captured step() was recorded: no
+        graph exists, so nothing of the capture may survive -- end_capture() has already taken the host counts back; forget the
+        captured parameter set and its baked-in counts and zero the replay counter / hyper-parameter slots of the control block
+        (the eager controlled kernel adds ctl[4] to its step count: a stale non-zero value would bias-correct every later eager
+        step wrongly, and a later load_state_dict would try to resume into a captured step that does not exist)."""
+        if self._capturing:
+            self.end_capture()
+        self._graph_params = []
+        self._graph_base = {}
+        self._graph_lr = None
+        self._ctl[4:8].zero_()
+
     def replay_begin(self):
         """Before a graph replay: hand the current learning rate / weight decay to the device (one tiny copy, only when they changed)."""
         g = self.param_groups[0]

@@ -749,7 +749,10 @@ class _MHA(torch.autograd.Function):
             nws = lib_.mmae_mha_bwd_fused_ws_floats(qseg.B, H, qseg.nseg, lse.shape[1], qseg.max_rows)
         else:
             nws = lib_.mmae_mha_bwd_ws_floats(H, lse.shape[1])
-        delta = torch.empty(nws, dtype=lse.dtype, device=lse.device)
+        # the fused kernel's workspace (row constants + fp32 partial dQ tiles of the tiles met in several key passes: ~0.47 GB at the bench
+        # shape) is scratch that lives for ONE launch: every layer's backward on a stream reuses one buffer (launches on a stream are
+        # ordered) instead of a fresh allocation per layer -- and per layer of a captured graph's private pool
+        delta = _mha_ws(nws, lse.dtype, lse.device) if fused else torch.empty(nws, dtype=lse.dtype, device=lse.device)
         es = qt.element_size()
         call("mmae_mha_bwd_fused" if fused else ("mmae_mha_bwd_variant" if variant else "mmae_mha_bwd"), dt(qt), dh, qseg.B, H, qseg.nseg,
              ctypes.c_void_p(qt.data_ptr() + qcol * es), ctypes.c_void_p(kv.data_ptr() + kcol * es),
@@ -760,6 +763,22 @@ class _MHA(torch.autograd.Function):
              gkv.stride(0), qt.shape[0], ptr(qseg.start), ptr(qseg.length), ptr(kseg.start), ptr(kseg.length),
              qseg.max_rows, kseg.max_rows, scale, empty_mode, *((variant,) if variant else ()), stream())
         return gq, (None if same else gkv), None, None, None, None, None, None, None, None, None, None
+
+
+_MHA_WS = {}
+
+
+def _mha_ws(n: int, dtype, device) -> torch.Tensor:
+    """One scratch buffer per (device, stream, dtype), grown on demand; contents are dead between launches.  Inside a graph capture
+    the buffer comes from the capture's own pool (a cached tensor must not outlive or predate the graph that bakes its address in)."""
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=dtype, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, dtype)
+    buf = _MHA_WS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=dtype, device=device)
+        _MHA_WS[key] = buf
+    return buf[:n]
 
 
 MHA_SELF_VARIANT = 0       # variant of mha_self calls that pass none (0 = product kernels; tools/tuning_env.py sets it for A/B runs)

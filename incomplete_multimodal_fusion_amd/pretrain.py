@@ -316,12 +316,10 @@ class PretrainStep:
             ok, why = self.reducer.capturable()             # (after the warm-up steps: the first one agrees the unused-parameter set)
             if not ok:
                 raise NotImplementedError("capture(): the gradient reducer cannot be captured -- " + why)
-            if self.reducer.collective:
-                # the process group's watchdog thread polls the events of the warm-up steps' collectives until it has seen each one
-                # complete (they all have: synchronize above); an event query while this thread captures aborts the process on this
-                # stack, so give its polling loop (100 ms period) time to drop them -- collectives issued during capture are not polled
-                import time
-                time.sleep(0.5)
+            # every collective the warm-up steps issued must be complete AND retired by the process group's watchdog thread before this
+            # thread starts capturing (the watchdog polls the events of earlier collectives; such a poll during a capture aborted the
+            # process on this stack).  Deterministic hand-off, no fixed sleep: dp.GradAllReducer.quiesce()
+            self.reducer.quiesce()
         if tuning:
             tun.tuning_enable(False)                         # an unseen shape must not start timing runs inside the capture
         self.model.mask_draws = self._draws
@@ -340,6 +338,7 @@ class PretrainStep:
             self.model.mask_draws = None
             self._draws = None
             self._graph = None
+            self.opt.abort_capture()                         # (also when the failure came AFTER the captured opt.step() was recorded)
             raise
         finally:
             self.model.check_masks = check
@@ -347,6 +346,8 @@ class PretrainStep:
             if tuning:
                 tun.tuning_enable(True)
         self._graph = graph
+        if self.reducer is not None:
+            self.reducer.captured = True                     # its stats / exposed_ms() describe eager steps only
         return self
 
     def _next_draw(self):

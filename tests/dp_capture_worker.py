@@ -33,11 +33,16 @@ def main():
     assert red_e.collective and len(red_e.buckets) > 2
     ok0, why0 = red_g.capturable()                    # before any step: the unused-parameter set is not agreed yet
     losses_e = [float(step_e(x, task_masks=masks)["loss"]) for _ in range(6)]
+    # many collectives still in flight when capture() is entered: nothing below waits for them -- capture()'s own hand-off
+    # (GradAllReducer.quiesce: handles complete, barrier, watchdog retirement read from c10d's flight recorder) has to
+    junk = torch.randn(1 << 22, device=dev)
+    inflight = [torch.distributed.all_reduce(junk, async_op=True) for _ in range(64)]
     step_g.capture(x, masks, warmup=2)
+    assert all(w.is_completed() for w in inflight)
     losses_g = [float(step_g.replay()["loss"]) for _ in range(4)]
     torch.cuda.synchronize()
     print(json.dumps({
-        "capturable_before_first_step": ok0, "why": why0, "buckets": len(red_g.buckets), "sent_buckets": red_e.stats["buckets"],
+        "quiesce": red_g.last_quiesce, "exposed_after_capture": red_g.exposed_ms(), "capturable_before_first_step": ok0, "why": why0, "buckets": len(red_g.buckets), "sent_buckets": red_e.stats["buckets"],
         "losses_eager": losses_e[2:], "losses_replay": losses_g,
         "master_equal": bool(torch.equal(opt_g.master, opt_e.master)), "exp_avg_equal": bool(torch.equal(opt_g.exp_avg, opt_e.exp_avg)),
         "steps": [opt_e.steps, opt_g.steps]}), flush=True)

@@ -133,4 +133,7 @@ def test_captured_step_with_the_rccl_reducer_replays_like_eager():
     assert not d["capturable_before_first_step"] and "eager step" in d["why"]
     assert d["sent_buckets"] == d["buckets"] > 2
     assert d["losses_replay"] == d["losses_eager"], d
+    # the hand-off into the capture was deterministic (no fixed sleep): completion established, then the watchdog's retirement observed
+    assert d["quiesce"]["method"] in ("flight_recorder", "watchdog_periods") and d["quiesce"]["handles"] > 0, d["quiesce"]
+    assert d["exposed_after_capture"] is None
     assert d["master_equal"] and d["exp_avg_equal"] and d["steps"] == [6, 6]

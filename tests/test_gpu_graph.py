@@ -163,6 +163,42 @@ def test_failed_capture_leaves_the_step_eager_and_unchanged():
         step.capture(x, None)
 
 
+def test_capture_that_fails_after_the_optimizer_step_leaves_no_graph_state():
+    """a capture that raises AFTER opt.step() was recorded used to leave _graph_params / _graph_base populated and the
+    control block's replay slots dirty -- a later resume then hit 'resuming into a captured step' or bias-corrected every eager
+    step with a stale replay count.  engine.abort_capture() (called by PretrainStep.capture's except path) must leave the engine
+    exactly as an engine that never captured: same loss trajectory as an untouched twin, resume allowed."""
+    import copy
+    base, x, masks = _setup(11)
+    model, opt, step = _step(base)
+    model_t, opt_t, step_t = _step(copy.deepcopy(base))               # the twin never captures
+    for s_ in (step, step_t):
+        s_(x, task_masks=masks)
+    orig = step._optimizer_step
+    calls = [0]
+
+    def step_then_fail():
+        calls[0] += 1
+        r = orig()
+        if calls[0] == 2:                              # call 1: the eager warm-up step; call 2: inside the capture, AFTER opt.step() was recorded
+            raise RuntimeError("injected failure behind the optimizer step")
+        return r
+    step._optimizer_step = step_then_fail
+    with pytest.raises(RuntimeError, match="behind the optimizer step"):
+        step.capture(x, masks, warmup=1)
+    step._optimizer_step = orig
+    step_t(x, task_masks=masks)                        # the twin takes the warm-up step too
+    torch.cuda.synchronize()
+    assert step._graph is None and opt._graph_params == [] and opt._graph_base == {} and opt._graph_lr is None
+    assert float(opt._ctl[4:8].abs().max()) == 0.0
+    assert opt.steps == opt_t.steps and all(v == opt.steps for v in opt._pstep.values())
+    opt.load_state_dict(opt.state_dict())              # a resume must not see a captured step
+    a = [float(step(x, task_masks=masks)["loss"]) for _ in range(3)]
+    b = [float(step_t(x, task_masks=masks)["loss"]) for _ in range(3)]
+    assert a == b, (a, b)
+    assert torch.equal(opt.master, opt_t.master)
+
+
 def test_captured_step_with_padded_feedforward_replays_bitwise(monkeypatch):
     """The padded-FeedForward route (odd GEGLU width on the own GEMM: engine.padded_ff) inside a captured step: the refresh of the padded
     copies (mmae_pad_copy_bf16_batched) is one of the captured launches, so the replays must track the weight updates exactly like the
