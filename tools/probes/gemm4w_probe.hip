@@ -1,0 +1,318 @@
+// Go / no-go probe for VERDICT r5 item 1: the FF1-shaped GEMM C[M, N] = A[M, K] . W[N, K]^T (bf16 in / out, fp32 accumulate) with FOUR waves per
+// workgroup -- one per SIMD -- each owning a 128 x 128 wave tile whose 256 accumulator registers sit in the AGPR half of the unified
+// register file (the 8-wave product kernel, csrc/gemm.hip: 128 x 64 wave tiles, 245 VGPRs / 0 AGPRs).  Per K-tile of 64 a workgroup then
+// reads 4 x 32 KB = 128 KB of fragments from LDS instead of 8 x 24 KB = 192 KB, and passes ONE workgroup barrier instead of eight.
+// tools/probes/gemm4w_issue_probe.hip measured what one wave per SIMD can sustain with its own loads between its own MFMAs (no partner
+// wave to hide them): 64 MFMAs + 16 ds_read_b128 + 8 LDS-DMA + 1 barrier = 1270 clocks per 1024 of matrix pipe, 1674 TFLOP/s chip-wide with
+// L2-resident operands and no C stores -- against ~1460-1500 for the 8-wave K-loop under the same conditions.
+//
+// Structure.  256 x 256 x 64 tiles, persistent (256 workgroups walk the tiles in the product kernel's XCD-aware order), operands by
+// LDS-DMA into two 64 KB buffers (128-byte rows, swizzled on the source address, b128 fragment reads conflict-free), fragments
+// double-buffered in registers by k-step (2 sets x (8 A + 8 W) fragments = 128 VGPRs):
+//     phase (t, 0): 64 MFMAs from set 0 = fragments (t, k-step 0); meanwhile set 1 <- fragments (t, k-step 1) out of buffer t & 1
+//     s_waitcnt lgkmcnt(0) + vmcnt(tile t + 1 landed); s_barrier                       <- the ONE barrier of the K-tile
+//     phase (t, 1): 64 MFMAs from set 1; meanwhile set 0 <- fragments (t + 1, k-step 0) out of the OTHER buffer, and the 16 LDS-DMA pieces
+//                   of K-tile t + 2 go into buffer t & 1 (every wave has read its last fragment of K-tile t before the barrier)
+// hipcc cannot allocate this by itself (340-530 bytes of scratch per lane, accumulators copied between the halves of the file): the MFMAs
+// are asm statements with the accumulator constrained to the AGPR class and accumulated in place (cdna_hip_programming.md 5.7).
+// W sits in LDS in a permuted row order (MFMA column j of n-tile ni = W row 8 j + ni of the wave's 128) so that a lane holds 8 CONSECUTIVE
+// output columns: one 16-byte store per (row, lane), 4 rows x 256 contiguous bytes per store instruction.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/gemm4w_probe.hip -o /tmp/gemm4w && /tmp/gemm4w [M N diag]
+//   diag (timing only, wrong results): 1 = every tile loads the operands of tile (0, 0) (all DMA hit L2); 2 = C stores dropped; 3 = both
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define LDS_AS __attribute__((address_space(3)))
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#ifndef STORE_AUX
+#define STORE_AUX 2          // nt: C is written once and never read here
+#endif
+#ifndef DMA_FIRST
+#define DMA_FIRST 1          // 1: the 16 DMA pieces of a K-tile go out four per MFMA row group behind the first four groups of phase 1; 0: two behind every group
+#endif
+
+#define MFMA_ACC(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define MFMA_ZERO(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b))
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {          // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ bf16x8 lds8(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+struct TileXY { int tm, tn; };
+// the product kernel's order (csrc/gemm.hip tile_of): XCD group x = workgroup % 8 owns M-panels [m0, m1), walked in chunks of <= 8 N-tiles
+__device__ __forceinline__ TileXY tile_of(int x, int i, int ntm, int ntn) {
+    const int q = ntm / 8, r = ntm % 8;
+    const int m0 = x * q + (x < r ? x : r), rows = q + (x < r ? 1 : 0);
+    const int GN = ntn < 8 ? ntn : 8, nc = ntn / GN, rem = ntn - nc * GN, full = nc * rows * GN;
+    TileXY t;
+    if (i < full) { const int c = i / (rows * GN), rr = i - c * rows * GN; t.tm = m0 + rr / GN; t.tn = c * GN + rr % GN; }
+    else { const int rr = i - full; t.tm = m0 + rr / rem; t.tn = nc * GN + rr % rem; }
+    return t;
+}
+__device__ __forceinline__ int tiles_of_xcd(int x, int ntm, int ntn) { return (ntm / 8 + (x < ntm % 8 ? 1 : 0)) * ntn; }
+
+struct Src { unsigned nA, nW; int sA, sW; };       // record counts (0: the tile does not exist, DMA zero-fills) + this wave's scalar byte origins
+struct Lane {
+    char* lds;
+    const bf16* A; const bf16* W; bf16* C;
+    int voffA, voffW;            // per-lane DMA source offsets of a piece (8 LDS rows x 128 B)
+    int rdA, rdW;                // fragment read offsets inside a buffer, k-step 0 (k-step 1: ^ 64)
+    int voffC, ldc2, lda2, ldw2;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ void dma(const void* base, unsigned nrec, int voff, int soff, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc(base, nrec), (LDS_AS void*)dst, 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
+}
+// piece q (0..15) of this wave's share of K-tile kt into buffer buf: q < 8 -> A rows 64 wave + 8 q .. + 7; q >= 8 -> W LDS rows 64 wave + 8 (q - 8) .. + 7
+// (LDS row 16 ni + j of a wave column's 128 = W row 8 j + ni: piece (ni, half) holds j = 8 half .. + 7, i.e. source rows 64 half + ni + 8 pr)
+template <int Q>
+__device__ __forceinline__ void stage_piece(const Lane& L, const Src& s, int kt, int buf, int wave) {
+    if (Q < 8) {
+        dma(L.A, s.nA, L.voffA, s.sA + 8 * Q * L.lda2 + kt * 128, L.lds + buf * 65536 + (64 * wave + 8 * Q) * 128);
+    } else {
+        constexpr int q = Q - 8;                                   // LDS rows 64 wave + 8 q ..: n-tile (4 (wave & 1) + q / 2) of wave column wave >> 1, half q & 1
+        dma(L.W, s.nW, L.voffW, s.sW + ((q >> 1) + 64 * (q & 1)) * L.ldw2 + kt * 128, L.lds + buf * 65536 + 32768 + (64 * wave + 8 * q) * 128);
+    }
+}
+
+struct Frags { bf16x8 a[2][8], w[2][8]; };
+
+// refill read #R (0..15) of fragment set S for k-step KS out of buffer buf: the W fragments first (a phase's first MFMA group needs all eight)
+template <int S, int KS, int R>
+__device__ __forceinline__ void refill(const Lane& L, int buf, Frags& f) {
+    const char* base = L.lds + buf * 65536;
+    if (R < 8) f.w[S][R] = lds8(base + (L.rdW ^ (64 * KS)) + R * 2048);
+    else f.a[S][R - 8] = lds8(base + (L.rdA ^ (64 * KS)) + (R - 8) * 2048);
+}
+
+template <int S, bool ZERO, int I>
+__device__ __forceinline__ void mfma_row(const Frags& f, f32x4 (&acc)[8][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (ZERO) MFMA_ZERO(acc[I][j], f.a[S][I], f.w[S][j]); else MFMA_ACC(acc[I][j], f.a[S][I], f.w[S][j]);
+    }
+}
+
+// phase (t, 0): MFMAs from set 0; set 1 <- (t, k-step 1) out of buffer b
+template <bool ZERO>
+__device__ __forceinline__ void phase0(const Lane& L, int b, Frags& f, f32x4 (&acc)[8][8]) {
+    // the 16 refill reads go out behind the first six MFMA row groups (3 3 3 3 2 2): the last of them has two row groups (256 clocks) to
+    // land before the lgkmcnt(0) in front of the barrier (after it other waves overwrite this buffer)
+#define P0_R(R) refill<1, 1, R>(L, b, f);
+    mfma_row<0, ZERO, 0>(f, acc); P0_R(0) P0_R(1) P0_R(2)
+    mfma_row<0, ZERO, 1>(f, acc); P0_R(3) P0_R(4) P0_R(5)
+    mfma_row<0, ZERO, 2>(f, acc); P0_R(6) P0_R(7) P0_R(8)
+    mfma_row<0, ZERO, 3>(f, acc); P0_R(9) P0_R(10) P0_R(11)
+    mfma_row<0, ZERO, 4>(f, acc); P0_R(12) P0_R(13)
+    mfma_row<0, ZERO, 5>(f, acc); P0_R(14) P0_R(15)
+    mfma_row<0, ZERO, 6>(f, acc);
+    mfma_row<0, ZERO, 7>(f, acc);
+#undef P0_R
+#define P0_STEP(I)
+#undef P0_STEP
+}
+// phase (t, 1): MFMAs from set 1; set 0 <- (t + 1, k-step 0) out of buffer b ^ 1; the wave's 16 pieces of K-tile (s2, kt2) into buffer b
+__device__ __forceinline__ void phase1(const Lane& L, const Src& s2, int kt2, int b, int wave, Frags& f, f32x4 (&acc)[8][8]) {
+#define P1_R(I) refill<0, 0, 2 * I>(L, b ^ 1, f); refill<0, 0, 2 * I + 1>(L, b ^ 1, f);
+#define P1_D(Q) stage_piece<Q>(L, s2, kt2, b, wave);
+#if DMA_FIRST
+    // all 16 pieces behind the first four row groups: each then has at least ~1500 clocks before the next K-tile's barrier asks for it
+    mfma_row<1, false, 0>(f, acc); P1_R(0) P1_D(0) P1_D(1) P1_D(2) P1_D(3)
+    mfma_row<1, false, 1>(f, acc); P1_R(1) P1_D(4) P1_D(5) P1_D(6) P1_D(7)
+    mfma_row<1, false, 2>(f, acc); P1_R(2) P1_D(8) P1_D(9) P1_D(10) P1_D(11)
+    mfma_row<1, false, 3>(f, acc); P1_R(3) P1_D(12) P1_D(13) P1_D(14) P1_D(15)
+    mfma_row<1, false, 4>(f, acc); P1_R(4)
+    mfma_row<1, false, 5>(f, acc); P1_R(5)
+    mfma_row<1, false, 6>(f, acc); P1_R(6)
+    mfma_row<1, false, 7>(f, acc); P1_R(7)
+#else
+    mfma_row<1, false, 0>(f, acc); P1_R(0) P1_D(0) P1_D(1)
+    mfma_row<1, false, 1>(f, acc); P1_R(1) P1_D(2) P1_D(3)
+    mfma_row<1, false, 2>(f, acc); P1_R(2) P1_D(4) P1_D(5)
+    mfma_row<1, false, 3>(f, acc); P1_R(3) P1_D(6) P1_D(7)
+    mfma_row<1, false, 4>(f, acc); P1_R(4) P1_D(8) P1_D(9)
+    mfma_row<1, false, 5>(f, acc); P1_R(5) P1_D(10) P1_D(11)
+    mfma_row<1, false, 6>(f, acc); P1_R(6) P1_D(12) P1_D(13)
+    mfma_row<1, false, 7>(f, acc); P1_R(7) P1_D(14) P1_D(15)
+#endif
+#undef P1_R
+#undef P1_D
+#define P1_STEP(I)
+#undef P1_STEP
+}
+#define MID_BARRIER(vm)                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+    VMCNT(vm);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    __builtin_amdgcn_s_barrier();                                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+// the wave's 128 x 128 tile -> C: lane (j, g), register r of acc[i][ni] = C[16 i + 4 g + r][8 j + ni]
+__device__ __forceinline__ void store_tile(f32x4 (&acc)[8][8], const Lane& L, unsigned nC, int corigin) {
+    const __amdgpu_buffer_rsrc_t rs = rsrc(L.C, nC);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // MFMA D -> the compiler's v_accvgpr_read of it: hipcc pads nothing behind an asm MFMA (cdna_hip_programming.md 5.7 item 2); the wait
+        // states sit in a statement that NAMES the row's accumulators, so no read of them can be scheduled above it
+        asm volatile("s_nop 15" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u32x4 v;
+            v[0] = pack2(acc[i][0][r], acc[i][1][r]); v[1] = pack2(acc[i][2][r], acc[i][3][r]);
+            v[2] = pack2(acc[i][4][r], acc[i][5][r]); v[3] = pack2(acc[i][6][r], acc[i][7][r]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, L.voffC, __builtin_amdgcn_readfirstlane(corigin + (16 * i + r) * L.ldc2), STORE_AUX);
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, int M, int N, int diag) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntm = M / 256, ntn = N / 256;
+    const int x = blockIdx.x & 7, jw = blockIdx.x >> 3, nper = gridDim.x >> 3;
+    const int txcd = tiles_of_xcd(x, ntm, ntn);
+    const int ntile = (txcd - jw + nper - 1) / nper;
+    if (ntile <= 0) return;
+    const unsigned szA = (unsigned)((long)M * K * 2), szW = (unsigned)((long)N * K * 2), szC = (diag & 2) ? 0u : (unsigned)((long)M * N * 2);
+    Lane L;
+    L.lds = lds; L.A = A; L.W = W; L.C = C;
+    L.lda2 = K * 2; L.ldw2 = K * 2; L.ldc2 = N * 2;
+    {
+        const int pr = lane >> 3, ch = lane & 7, j = lane & 15, g = lane >> 4;
+        L.voffA = pr * L.lda2 + 16 * (ch ^ pr);
+        L.voffW = 8 * pr * L.ldw2 + 16 * (ch ^ pr);                  // the 8 LDS rows of a W piece are MFMA columns j0 .. j0 + 7 = W rows 8 apart
+        L.rdA = (128 * wr + j) * 128 + 16 * (g ^ (j & 7));
+        L.rdW = 32768 + (128 * wc + j) * 128 + 16 * (g ^ (j & 7));
+        L.voffC = 4 * g * L.ldc2 + 16 * j;
+    }
+    auto origin = [&](Src& s, TileXY t, bool real) {
+        if (diag & 1) { t.tm = 0; t.tn = 0; }
+        s.nA = real ? szA : 0u; s.nW = real ? szW : 0u;
+        s.sA = (t.tm * 256 + 64 * wave) * L.lda2;
+        // this wave stages LDS rows 64 wave .. + 63 of the W image = wave column wave >> 1, n-tiles 4 (wave & 1) .. + 3
+        s.sW = (t.tn * 256 + 128 * (wave >> 1) + 4 * (wave & 1)) * L.ldw2;
+    };
+    auto cptr = [&](TileXY t) { return (t.tm * 256 + 128 * wr) * L.ldc2 + (t.tn * 256 + 128 * wc) * 2; };
+    f32x4 acc[8][8];
+    Frags f;
+    constexpr int NT = K / 64;
+    static_assert(NT >= 3, "K >= 192");
+    TileXY cur = tile_of(x, jw, ntm, ntn);
+    Src c, cn;
+    origin(c, cur, true);
+    // prologue: K-tiles 0 and 1 of the first tile; fragment set 0 <- (0, k-step 0)
+#define STAGE_ALL(src, kt, buf) stage_piece<0>(L, src, kt, buf, wave); stage_piece<1>(L, src, kt, buf, wave); stage_piece<2>(L, src, kt, buf, wave); \
+    stage_piece<3>(L, src, kt, buf, wave); stage_piece<4>(L, src, kt, buf, wave); stage_piece<5>(L, src, kt, buf, wave); stage_piece<6>(L, src, kt, buf, wave); \
+    stage_piece<7>(L, src, kt, buf, wave); stage_piece<8>(L, src, kt, buf, wave); stage_piece<9>(L, src, kt, buf, wave); stage_piece<10>(L, src, kt, buf, wave); \
+    stage_piece<11>(L, src, kt, buf, wave); stage_piece<12>(L, src, kt, buf, wave); stage_piece<13>(L, src, kt, buf, wave); stage_piece<14>(L, src, kt, buf, wave); \
+    stage_piece<15>(L, src, kt, buf, wave);
+    STAGE_ALL(c, 0, 0)
+    STAGE_ALL(c, 1, 1)
+    VMCNT(16);
+    __builtin_amdgcn_s_barrier();
+#define FILL0(R) refill<0, 0, R>(L, 0, f);
+    FILL0(0) FILL0(1) FILL0(2) FILL0(3) FILL0(4) FILL0(5) FILL0(6) FILL0(7) FILL0(8) FILL0(9) FILL0(10) FILL0(11) FILL0(12) FILL0(13) FILL0(14) FILL0(15)
+#undef FILL0
+    for (int it = 0; it < ntile; ++it) {
+        const bool has_next = it + 1 < ntile;
+        const TileXY nxt = tile_of(x, jw + (has_next ? it + 1 : it) * nper, ntm, ntn);
+        origin(cn, nxt, has_next);
+        // K-tile 0 (buffer 0 when NT is even; the stream of K-tiles alternates buffers across tiles, so NT must be even here)
+        phase0<true>(L, 0, f, acc);
+        MID_BARRIER(0)
+        phase1(L, c, 2, 0, wave, f, acc);
+        for (int t = 1; t < NT - 2; ++t) {
+            phase0<false>(L, t & 1, f, acc);
+            MID_BARRIER(0)
+            phase1(L, c, t + 2, t & 1, wave, f, acc);
+        }
+        phase0<false>(L, (NT - 2) & 1, f, acc);
+        MID_BARRIER(0)
+        phase1(L, cn, 0, (NT - 2) & 1, wave, f, acc);
+        phase0<false>(L, (NT - 1) & 1, f, acc);
+        MID_BARRIER(0)
+        phase1(L, cn, 1, (NT - 1) & 1, wave, f, acc);
+        store_tile(acc, L, szC, cptr(cur));
+        cur = nxt; c = cn;
+    }
+    VMCNT(0);
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 163840, N = argc > 2 ? atoi(argv[2]) : 4096;
+    constexpr int K = 768;
+    static_assert((K / 64) % 2 == 0, "even number of K-tiles (buffer parity carries across tiles)");
+    if (M % 256 || N % 256) { printf("M, N must be multiples of 256\n"); return 1; }
+    std::vector<bf16> hA((size_t)M * K), hW((size_t)N * K);
+    srand(1);
+    for (auto& x : hA) x = (bf16)((rand() % 2001 - 1000) / 1000.0f);
+    for (auto& x : hW) x = (bf16)((rand() % 2001 - 1000) / 1000.0f);
+    bf16 *A, *W, *C;
+    hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&C, (size_t)M * N * 2);
+    hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(C, 0xff, (size_t)M * N * 2);
+    const int diag = argc > 3 ? atoi(argv[3]) : 0;
+    const long tiles = (long)(M / 256) * (N / 256);
+    const int nper = tiles >= 256 ? 32 : (int)((tiles + 7) / 8);
+    const dim3 grid(8 * nper), blk(256);
+    const size_t ldsb = 131072;
+    if (hipFuncSetAttribute((const void*)gemm4w_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) { printf("LDS attribute failed\n"); return 1; }
+    auto launch = [&](int dg) { gemm4w_kernel<K><<<grid, blk, ldsb>>>(A, W, C, M, N, dg); };
+    launch(0);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    double worst = 0; long bad = 0, checked = 0;
+    auto check = [&](long m, long n, bf16 got) {
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)(float)hA[m * K + k] * (double)(float)hW[n * K + k];
+        const double e = fabs((double)(float)got - ref) / fmax(1.0, fabs(ref));
+        worst = fmax(worst, e); bad += e > 1e-2; ++checked;
+    };
+    std::vector<bf16> row(N);
+    const long tl[4][2] = {{0, 0}, {M / 256 - 1, N / 256 - 1}, {(M / 256) / 2 + 1, (N / 256) / 2 - 1}, {(M / 256) / 3, 1 % (N / 256)}};
+    for (auto& t : tl)
+        for (int r = 0; r < 256; ++r) {
+            const long m = t[0] * 256 + r;
+            hipMemcpy(row.data(), C + m * N, (size_t)N * 2, hipMemcpyDeviceToHost);
+            for (int cc = 0; cc < 256; ++cc) check(m, t[1] * 256 + cc, row[t[1] * 256 + cc]);
+        }
+    for (int t = 0; t < 2048; ++t) {
+        const long m = (long)(rand() % M), n = rand() % N;
+        bf16 got; hipMemcpy(&got, C + m * N + n, 2, hipMemcpyDeviceToHost);
+        check(m, n, got);
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) launch(diag);
+    float best = 1e9f, tot = 0;
+    const int rounds = 5, it = 10;
+    for (int r = 0; r < rounds; ++r) {
+        hipEventRecord(e0);
+        for (int i = 0; i < it; ++i) launch(diag);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = fminf(best, ms / it); tot += ms / it;
+    }
+    const double fl = 2.0 * M * N * K;
+    printf("4-wave 128x128-wave-tile GEMM (persistent, AGPR accumulators)  M %d N %d K %d diag %d: mean %.1f us = %.0f TFLOP/s, best round %.1f us = %.0f TFLOP/s "
+           "(gate 1450; random [-1,1) operands)\n  check: %ld entries, %ld beyond 1e-2, max rel err %.2e\n",
+           M, N, K, diag, tot / rounds * 1e3, fl / (tot / rounds * 1e-3) / 1e12, best * 1e3, fl / (best * 1e-3) / 1e12, checked, bad, worst);
+    return bad ? 2 : 0;
+}
