@@ -531,12 +531,14 @@ def main():
                                               # step once per 11 steps (round 4's every-7th was phase-locked: the same 26 launches each step)
     for _ in range(args.warmup):
         losses = step(x)
+    calls0 = dict(ops.CALLS)
     ops.set_kernel_timer([prof, prof_ln, prof_gemm])
     # roofline_block: HIP events around ONE encoder layer (Block_Fusion + Block) of the middle of the stack, forward and backward
     block_layer = min(6, model.depth - 1)
     model.layer_timer = ops.LayerTimer(block_layer) if (model.depth > 1 and args.block_timer) else None
     dt, losses, per_step_ms, ranks_dt, host_enqueue_ms = timed_region(step, x, args.steps, distributed, device)
     ops.set_kernel_timer(None)
+    calls_per_step = {k: round((ops.CALLS[k] - calls0[k]) / max(args.steps, 1), 1) for k in calls0}
     layer_timer, model.layer_timer = model.layer_timer, None
     loss_val = float(losses["loss"])
     assert loss_val == loss_val, "non-finite loss"
@@ -702,6 +704,14 @@ def main():
             out["mfma_busy_source"] = mb["source"] if mb is not None else None
             out["replayed_from"] = {"sq_step": rep_sq, "pmc_hbm": rep_hbm,
                                     "fields": "mfma_busy_pct, roofline_gemm <- sq_step; roofline.traffic, roofline_hbm.traffic, roofline_attention.traffic <- pmc_hbm"}
+        # which projections ran where (the own GEMM takes a projection from _OWN_GEMM_MIN_TILES output tiles on), and how the sample-head
+        # attention kernels split a sample's heads over workgroups (csrc/mha_sh.hip sh_heads_per_block: >= 256 workgroups when B allows)
+        heads = {"tiny": 3}.get(args.model, 8)
+        hpb = heads
+        while hpb > 1 and args.batch * (heads // hpb) < 256:
+            hpb = max(d for d in range(1, hpb) if heads % d == 0)
+        out["dispatch"] = {"launches_per_step": calls_per_step, "own_gemm_min_tiles": ops._OWN_GEMM_MIN_TILES,
+                           "attention_heads_per_workgroup": hpb, "attention_workgroups": args.batch * (heads // hpb)}
         out.update(dpdiag)
         out.update(leg_out)
         if world == 1 and not args.no_cpu_baseline:

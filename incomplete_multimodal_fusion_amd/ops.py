@@ -204,7 +204,8 @@ OWN_GEMM = 1          # bit 0: forward / input-gradient projections of supported
                       # rate, no change from 3 to 5 staging steps in flight), +4.7 ms in the step -> OFF by default.
                       # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
 _OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
-CALLS = {"mmae_gemm_nt": 0, "mmae_gemm_geglu": 0, "mmae_gemm_tn": 0}     # launches of the own GEMM entry points (tests assert engagement)
+CALLS = {"mmae_gemm_nt": 0, "mmae_gemm_geglu": 0, "mmae_gemm_tn": 0,      # launches of the own GEMM entry points (tests assert engagement)
+         "library_matmul_nt": 0}                                          # ... and the projections matmul_nt handed to the library instead
 
 
 _WARNED = set()
@@ -273,6 +274,7 @@ def matmul_nt(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
     """x @ w^T: the own kernel where it applies, the library GEMM (hipBLASLt through torch) otherwise."""
     if own_gemm_ok(x, w, out):
         return gemm_nt(x, w, out)
+    CALLS["library_matmul_nt"] += 1
     if out is not None:
         return torch.mm(x, w.t(), out=out)
     return torch.nn.functional.linear(x, w)
