@@ -41,17 +41,39 @@ namespace {
 __device__ __forceinline__ unsigned gm_pack2(float lo, float hi) {          // one v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
-// GELU of the FF1 + GEGLU epilogue (exact-erf GELU of the reference: F.gelu, DSI-MM/zorro_utils.py:115-118).  The epilogue is VALU-issue
-// bound, so the form with the fewest instructions that is still exact at the precision the result is stored in:
-//   GM_GELU_FAST 1 (default): x * sigma(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax on |x| <= 9, x^2 clamped there) to
-//     |gelu - x Phi(x)| <= 2.6e-5 for EVERY bf16 input: the product g = gelu(gate) * val is rounded to bf16 (relative 2^-9) right after, and
-//     the bf16-rounded gelu differs from the exact one's for 18 of the 2130 bf16 inputs with |gelu| > 0.02, by one ulp (tools/probes/
-//     gelu_form_check.py).  8 instructions (10 issue slots with the two 8-cycle transcendentals) against 13 (15).
-//   GM_GELU_FAST 0: x * Phi(x), Phi from one exp2 + one rcp (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) -- the approximation of rowops.hip's
-//     geglu kernels (fp32 mode and the un-fused path), with the 0.5 of erfc / 2 folded into the coefficients and
-//     x Phi(x) = max(x, 0) - |x| * (erfc(|x| / sqrt 2) / 2) for either sign.
+// GELU of the FF1 + GEGLU epilogue (exact-erf GELU of the reference: F.gelu, DSI-MM/zorro_utils.py:115-118).  Three forms, chosen at build time:
+//   GM_GELU_FAST 1 (default since round 5): x * sigma(x (c0 + c1 x^2 + c2 x^4)), coefficients fitted (minimax on |x| <= 9, x^2 clamped there) to
+//     |gelu - x Phi(x)| <= 2.6e-5 for EVERY bf16 input: the product g = gelu(gate) * val is rounded to bf16 (relative 2^-9) right after, and the
+//     bf16-rounded gelu differs from the correctly rounded erf form for 18 of the 17 745 bf16 gates with |gelu| >= 0.02, by one ulp -- asserted
+//     ON THE DEVICE over all 65 280 finite gates by tests/test_gpu_gemm.py::test_gemm_geglu_epilogue_gelu_over_every_bf16_gate.  9 instructions
+//     / 11 issue slots per gate.  A documented deviation: the fastest form measured.
+//   GM_GELU_LUT 1 (round 6, `make EXTRA=-DGM_GELU_LUT=1`): x * Phi(x) with Phi LOOKED UP -- the gate the product is formed from is a bf16 value,
+//     i.e. one of 65 536 numbers; Phi of the 2 x 2048 of them with |x| in [2^-12, 16) sits in LDS as fp32 (16 KB behind the tile buffers,
+//     csrc/gelu_phi_table.inc from tools/gen_phi_table.py: erfc in double, rounded once), the index is clamped (|x| < 2^-12: 0.5 +- 1e-4;
+//     |x| >= 16: exactly 1 / 0).  EXACT: 0 of the 17 745 gates differ from the correctly rounded erf form.  6 integer instructions + one
+//     ds_read_b32 + one multiply per gate (8 slots) -- and SLOWER: the 64-address gathers cost the LDS more than the 3 slots save
+//     (epilogue 200.5 vs 190.6 us per launch at the FF1 shape, step 155.5 vs 154.9 ms, three alternations on one box).  Not the default.
+//   GM_GELU_FAST 0: x * Phi(x), Phi from one exp2 + one rcp (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) -- the approximation of
+//     rowops.hip's geglu kernels (fp32 mode and the un-fused path); 13 instructions / 15 slots; +0.8 ms per step (round 5).
+#ifndef GM_GELU_LUT
+#define GM_GELU_LUT 0
+#endif
 #ifndef GM_GELU_FAST
 #define GM_GELU_FAST 1
+#endif
+#define GM_PHI_LDS 131072          // byte offset of the Phi table in LDS (EPI 1 only: 128 KB of tiles + 16 KB)
+#if GM_GELU_LUT
+__device__ const unsigned gm_phi_table[4096] = {
+#include "gelu_phi_table.inc"
+};
+// Phi of the bf16 value in bits [SH, SH + 16) of w
+template <int SH>
+__device__ __forceinline__ float gm_phi_lut(const char* lds, unsigned w) {
+    const int t = (int)__builtin_amdgcn_ubfe(w, SH, 15) - 0x3980;
+    const unsigned tc = (unsigned)min(max(t, 0), 2047);                      // one v_med3_i32
+    const unsigned idx = ((w >> (SH + 4)) & 0x800u) | tc;                 // sign bit -> bit 11: the negative half of the table
+    return *reinterpret_cast<const float*>(lds + GM_PHI_LDS + (idx << 2));
+}
 #endif
 __device__ __forceinline__ float gm_gelu(float x) {
 #if GM_GELU_FAST
@@ -202,6 +224,8 @@ __device__ __forceinline__ void store_half(const f32x4 (&acc)[8][4], const Lane&
                 const bf16x2 bv = __builtin_bit_cast(bf16x2, hv), bg = __builtin_bit_cast(bf16x2, hg);
 #if GM_EPI_DIAG == 1          // timing only: no GELU
                 const unsigned pr = gm_pack2((float)bg[0] * (float)bv[0], (float)bg[1] * (float)bv[1]);
+#elif GM_GELU_LUT
+                const unsigned pr = gm_pack2((float)bg[0] * gm_phi_lut<0>(L.lds, hg) * (float)bv[0], (float)bg[1] * gm_phi_lut<16>(L.lds, hg) * (float)bv[1]);
 #else
                 const unsigned pr = gm_pack2(gm_gelu((float)bg[0]) * (float)bv[0], gm_gelu((float)bg[1]) * (float)bv[1]);
 #endif
@@ -314,6 +338,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     TileXY cur = tile_of(x, jw, p.ntm, p.ntn);
     Ctx c, cn;
     origin(c, cur, true);
+#if GM_GELU_LUT
+    if (EPI == 1) {                                         // the Phi table: 16 pieces of 1 KiB, two per wave, OLDER than the tile pieces the vmcnt(6) below leaves in flight
+        gm_dma(gm_phi_table, 16384u, 16 * lane, 2048 * wave, lds + GM_PHI_LDS + 2048 * wave);
+        gm_dma(gm_phi_table, 16384u, 16 * lane, 2048 * wave + 1024, lds + GM_PHI_LDS + 2048 * wave + 1024);
+    }
+#endif
     stageA(L, c, 0, 0, 0, wave); stageW(L, c, 0, 0, 0, wave); stageW(L, c, 0, 0, 1, wave); stageA(L, c, 0, 0, 1, wave);
     stageA(L, c, 1, 1, 0, wave); stageW(L, c, 1, 1, 0, wave);
     GM_VMCNT(6);
@@ -369,10 +399,11 @@ bool gm_lds_opt_in(K kernel, int bytes, std::atomic<bool> (&done)[64]) {
 template <int EPI>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     static std::atomic<bool> attr_set[64];
-    if (!gm_lds_opt_in(gemm8p_kernel<EPI>, 131072, attr_set)) return MMAE_ERR_LAUNCH;
+    constexpr int ldsb = 131072 + ((EPI == 1 && GM_GELU_LUT) ? 16384 : 0);
+    if (!gm_lds_opt_in(gemm8p_kernel<EPI>, ldsb, attr_set)) return MMAE_ERR_LAUNCH;
     const long tiles = (long)a.ntm * a.ntn;
     const int nper = tiles >= 256 ? 32 : (int)((tiles + 7) / 8);          // workgroups per XCD group; one workgroup per CU (128 KB of LDS)
-    MMAE_LAUNCH((gemm8p_kernel<EPI>), dim3(8 * nper), dim3(512), 131072, st, a);
+    MMAE_LAUNCH((gemm8p_kernel<EPI>), dim3(8 * nper), dim3(512), ldsb, st, a);
     MMAE_CHECK_LAUNCH();
     return MMAE_OK;
 }
