@@ -281,6 +281,38 @@ __device__ __forceinline__ void stageW2(const Lane2& L, const Ctx2& c, int kt, i
     dma<K>(c.rsW, L.voffW, c.sW + (128 * half * K + kt * 64) * 2, L.lds + buf * 65536 + 32768 + row * 128);
     dma<K>(c.rsW, L.voffW, c.sW + ((128 * half + 64) * K + kt * 64) * 2, L.lds + buf * 65536 + 32768 + (row + 64) * 128);
 }
+// -DDMA_GROUP_A (round 6 experiment): waves 0..3 -- the wave group that runs one barrier AHEAD -- issue ALL LDS-DMA pieces (their own and those
+// of waves 4..7) and do all the counted waits; waves 4..7 issue none, so their rolled-epilogue stores share a vmcnt queue with nothing a
+// later wait needs (vmcnt retires in issue order: a DMA issued after a store is only counted complete once that store is).
+template <int K>
+__device__ __forceinline__ void stageA2g(const Lane2& L, const Ctx2& c, int kt, int buf, int hi, int wave) {
+#ifdef DMA_GROUP_A
+    if (wave < 4) {
+        stageA2<K>(L, c, kt, buf, hi, wave);
+        Ctx2 c2 = c; c2.sA += 32 * K * 2;
+        stageA2<K>(L, c2, kt, buf, hi, wave + 4);
+    }
+#else
+    stageA2<K>(L, c, kt, buf, hi, wave);
+#endif
+}
+template <int K>
+__device__ __forceinline__ void stageW2g(const Lane2& L, const Ctx2& c, int kt, int buf, int half, int wave) {
+#ifdef DMA_GROUP_A
+    if (wave < 4) {
+        stageW2<K>(L, c, kt, buf, half, wave);
+        Ctx2 c2 = c; c2.sW += 2 * K * 2;
+        stageW2<K>(L, c2, kt, buf, half, wave + 4);
+    }
+#else
+    stageW2<K>(L, c, kt, buf, half, wave);
+#endif
+}
+#ifdef DMA_GROUP_A
+#define VMCNT_G(dma, st) if (wave < 4) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (dma) + (st)) : "memory"); }
+#else
+#define VMCNT_G(dma, st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((dma) + (st)) : "memory")
+#endif
 struct Frags2 {
     bf16x8 a[4][2];                      // A fragments of the current 64-row group (a operand: row = m)
     bf16x8 wlo[2][2], whi[2][2];         // W fragments, n-tiles 0, 1 / 2, 3 (b operand: column j = W row 4 j + ni)
@@ -363,20 +395,20 @@ __device__ __forceinline__ void ktile2(const Lane2& L, const Ctx2& c1, int kt1, 
                                        const __amdgpu_buffer_rsrc_t& rsPrev, int cprev, const __amdgpu_buffer_rsrc_t& rsC, int ccur) {
     constexpr bool FIRST = KIND == 1, LAST = KIND == 3;
     load_frags2<0>(L, b, f);
-    stageW2<K>(L, c1, kt1, b ^ 1, 1, wave);
+    stageW2g<K>(L, c1, kt1, b ^ 1, 1, wave);
     if (FIRST) store_half<1, 0>(acc, L, rsPrev, cprev);
     PHASE_TAIL2(0, FIRST)
     load_frags2<1>(L, b, f);
-    stageA2<K>(L, c1, kt1, b ^ 1, 1, wave);
-    if (FIRST) VMCNT(32); else if (KIND == 2) VMCNT(16); else VMCNT(8);        // A-hi of THIS K-tile has landed
+    stageA2g<K>(L, c1, kt1, b ^ 1, 1, wave);
+    if (FIRST) { VMCNT_G(8, 24); } else if (KIND == 2) { VMCNT_G(8, 8); } else { VMCNT_G(8, 0); }        // A-hi of THIS K-tile has landed
     if (FIRST) store_half<1, 1>(acc, L, rsPrev, cprev);
     PHASE_TAIL2(1, FIRST)
     load_frags2<2>(L, b, f);
-    stageA2<K>(L, c2, kt2, b, 0, wave);
+    stageA2g<K>(L, c2, kt2, b, 0, wave);
     if (LAST) store_half<0, 0>(acc, L, rsC, ccur);
     PHASE_TAIL2(2, FIRST)
-    stageW2<K>(L, c2, kt2, b, 0, wave);
-    if (LAST) VMCNT(14); else if (FIRST) VMCNT(22); else VMCNT(6);             // A-lo, W half 0, W half 1 of the next K-tile have landed
+    stageW2g<K>(L, c2, kt2, b, 0, wave);
+    if (LAST) { VMCNT_G(6, 8); } else if (FIRST) { VMCNT_G(6, 16); } else { VMCNT_G(6, 0); }             // A-lo, W half 0, W half 1 of the next K-tile have landed
     if (LAST) store_half<0, 1>(acc, L, rsC, ccur);
     PHASE_TAIL2(3, FIRST)
 }
@@ -423,9 +455,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_persist_kernel(const bf16* __re
     TileXY cur = tile_of(wg, 0, ntm, ntn, nwg);
     Ctx2 c, cn;
     origin(c, cur, true);
-    stageA2<K>(L, c, 0, 0, 0, wave); stageW2<K>(L, c, 0, 0, 0, wave); stageW2<K>(L, c, 0, 0, 1, wave); stageA2<K>(L, c, 0, 0, 1, wave);
-    stageA2<K>(L, c, 1, 1, 0, wave); stageW2<K>(L, c, 1, 1, 0, wave);
-    VMCNT(6);
+    stageA2g<K>(L, c, 0, 0, 0, wave); stageW2g<K>(L, c, 0, 0, 0, wave); stageW2g<K>(L, c, 0, 0, 1, wave); stageA2g<K>(L, c, 0, 0, 1, wave);
+    stageA2g<K>(L, c, 1, 1, 0, wave); stageW2g<K>(L, c, 1, 1, 0, wave);
+    VMCNT_G(6, 0);
     __builtin_amdgcn_s_barrier();
     STAGGER(wr == 1);
     int cprev = 0;
