@@ -203,7 +203,9 @@ OWN_GEMM = 1          # bit 0: forward / input-gradient projections of supported
                       # bound by the latency of its operand stream: 1546 TFLOP/s with every DMA hitting L2, 1040 from HBM at a 75 % L2 hit
                       # rate, no change from 3 to 5 staging steps in flight), +4.7 ms in the step -> OFF by default.
                       # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
-_OWN_GEMM_MIN_TILES = 512     # below two tiles per CU the library's smaller tiles fill the chip better
+_OWN_GEMM_MIN_TILES = 256     # from one 256 x 256 output tile per CU on; below that the library's smaller tiles fill the chip better.  (512 until round 6:
+                              # at the reference's per-GPU batch, B = 64, that sent every N = 768 / 512 projection of the 40 960 rows to the library --
+                              # same-box A/B at B = 64: 44.94 / 45.01 ms per step at 512, 44.80 / 44.90 at 256, 44.85 / 44.72 at 128; B = 256 is not affected)
 CALLS = {"mmae_gemm_nt": 0, "mmae_gemm_geglu": 0, "mmae_gemm_tn": 0,      # launches of the own GEMM entry points (tests assert engagement)
          "library_matmul_nt": 0}                                          # ... and the projections matmul_nt handed to the library instead
 

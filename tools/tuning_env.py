@@ -14,6 +14,7 @@ The product package reads NO tuning variable itself (only MMAE_HIP_LIB, the libr
     MMAE_DEFER_SPLITK    ops.DEFER_SPLITK           0: one split-K sum launch per weight gradient instead of one per layer
     MMAE_MHA_FUSED_BWD   ops.MHA_FUSED_BWD          0: the dQ + dK/dV kernel pair instead of the fused attention backward
     MMAE_PAD_FF_MIN_TILES ops.PAD_FF_MIN_TILES      output tiles of FeedForward[3] from which the padded route is taken
+    MMAE_OWN_GEMM_MIN_TILES ops._OWN_GEMM_MIN_TILES output tiles from which a projection runs on the own GEMM (512 = two tiles per CU)
     MMAE_PAD_FF          ops.PAD_FF                 0: FeedForwards whose GEGLU width fits none of the own GEMM's tiles (ViT-L) stay on the library GEMMs
 """
 import os
@@ -40,6 +41,7 @@ def apply(verbose=True):
     put(ops, "PAD_FF", "MMAE_PAD_FF", flag)
     put(ops, "MHA_FUSED_BWD", "MMAE_MHA_FUSED_BWD", flag)
     put(ops, "PAD_FF_MIN_TILES", "MMAE_PAD_FF_MIN_TILES", int)
+    put(ops, "_OWN_GEMM_MIN_TILES", "MMAE_OWN_GEMM_MIN_TILES", int)
     put(mc, "FUSED_FINAL_CAST", "MMAE_FUSED_CAST", flag)
     put(mc, "FUSED_DECODER_CTX", "MMAE_FUSED_CTX", flag)
     put(mc, "DUAL_LAYERNORM", "MMAE_DUAL_LN", flag)
