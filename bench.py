@@ -251,6 +251,58 @@ def mfma_busy():
         return None
 
 
+def mfma_busy_live(args, timeout_s=170):
+    """MFMA-busy % of THIS command measured on THIS box (the replayed figure comes from a committed profile): a child
+    `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 2 --legs none` run BEFORE this process
+    touches the GPU (a counter pass in its own process, sequential: nothing shares the card with the timed region), condensed exactly as
+    tools/prof_summary.py's `sq` does: sum of busy cycles / (1024 SIMDs x sum of GRBM_GUI_ACTIVE / 8 XCDs) over every dispatch.  Returns
+    None when rocprofv3 is not on this machine; an {"error": ...} object -- never an exception -- when the pass fails or times out."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out_dir = tempfile.mkdtemp(prefix="mmae_pmc_", dir="/tmp")
+    steps = 2
+    cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", out_dir, "--",
+           sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--legs", "none",
+           "--block-timer", "0", "--batch", str(args.batch)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return {"error": "rocprofv3 pass exited with %d: %s" % (r.returncode, (r.stderr or "")[-200:])}
+        files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return {"error": "rocprofv3 pass wrote no counter_collection.csv"}
+        tot = collections.defaultdict(float)
+        gemm = collections.defaultdict(float)
+        seen, ns = set(), 0
+        for x in csv.DictReader(open(files[0])):
+            tot[x["Counter_Name"]] += float(x["Counter_Value"])
+            if "gemm8p_kernel<0>" in x["Kernel_Name"]:
+                gemm[x["Counter_Name"]] += float(x["Counter_Value"])
+            if x["Dispatch_Id"] not in seen:
+                seen.add(x["Dispatch_Id"])
+                ns += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+        simds = 1024.0 / 8.0
+        pct = lambda c: round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * c["GRBM_GUI_ACTIVE"]), 2) if c.get("GRBM_GUI_ACTIVE") else None
+        return {"pct": pct(tot), "gemm8p_kernel<0>_pct": pct(gemm), "kernel_ms_per_profiled_step": round(ns / 1e6 / (steps + 2), 2),
+                "pass_s": round(time.perf_counter() - t0, 1),
+                "source": "live: child `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 2 --legs none` "
+                          "on this box, before the timed region (all 4 steps of the pass counted)"}
+    except subprocess.TimeoutExpired:
+        return {"error": "rocprofv3 pass did not finish in %d s" % timeout_s}
+    except Exception as e:                                  # never lose the headline line over this leg
+        return {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
 def event_bracket_overhead_ms(device, n=96):
     """What a HIP-event bracket measures around NOTHING on a busy stream: the two event packets are each processed after
     the preceding work drains, so every bracket of ops.KernelTimer carries this constant on top of the kernel's own
@@ -435,8 +487,9 @@ def main():
                     help="main region: every sample draws its own mask row (packed variable-length segments)")
     ap.add_argument("--dropout", action="store_true", help="main region: random modality dropout (sample_tasks_uniformly: a "
                     "uniformly drawn non-empty modality subset per mask row, the others get no tokens)")
-    ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3,graph; "
-                    "'auto' = both at N = 1 with default main settings, none otherwise; 'none'")
+    ap.add_argument("--legs", default="auto", help="secondary legs timed after the main region: comma list of pcie,c3,graph (+ mfma: the live "
+                    "rocprofv3 MFMA-busy pass in a child process BEFORE the timed region); 'auto' = all at N = 1 with default main settings, none "
+                    "otherwise; 'none'")
     ap.add_argument("--clip-grad", dest="clip_grad", type=float, default=0.0, help="> 0: device-side global-norm clipping")
     ap.add_argument("--block-timer", dest="block_timer", type=int, default=1, help="1: HIP-event brackets around encoder layer 6 "
                     "(four events per step) for roofline_block")
@@ -459,6 +512,11 @@ def main():
     import torch.distributed as dist
     from incomplete_multimodal_fusion_amd import dp, ops
     from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
+    # the live MFMA-busy pass: only for the default invocation at N = 1 (`--legs auto`), and before anything here touches the GPU
+    headline_cfg = args.domains == "s1,s2,dem" and args.fusion_blocks and args.contra == "dino" and args.model == "base" and \
+        not (args.staging or args.per_sample or args.dropout or args.fp32) and args.batch == 256
+    live_busy = mfma_busy_live(args) if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and
+                                         (args.legs == "auto" and headline_cfg or "mfma" in args.legs.split(","))) else None
     if args.tuning_env:
         from tools import tuning_env
         tuning_env.apply()
@@ -703,14 +761,23 @@ def main():
             out["mfma_busy_pct"] = mb["pct"] if (mb is not None and sq_ok) else None
             out["mfma_busy_source"] = mb["source"] if mb is not None else None
             out["replayed_from"] = {"sq_step": rep_sq, "pmc_hbm": rep_hbm,
-                                    "fields": "mfma_busy_pct, roofline_gemm <- sq_step; roofline.traffic, roofline_hbm.traffic, roofline_attention.traffic <- pmc_hbm"}
+                                    "fields": "mfma_busy_pct (unless measured live), roofline_gemm <- sq_step; roofline.traffic, roofline_hbm.traffic, roofline_attention.traffic <- pmc_hbm"}
+        if live_busy is not None:
+            # measured on THIS box by a counter pass of this command (mfma_busy_live); when it succeeded it IS the line's MFMA-busy figure,
+            # the replayed one is kept beside it
+            out["mfma_busy_live"] = live_busy
+            if live_busy.get("pct") is not None:
+                out["mfma_busy_pct_replayed"] = out.get("mfma_busy_pct")
+                out["mfma_busy_pct"] = live_busy["pct"]
+                out["mfma_busy_source"] = "live (mfma_busy_live)"
         # which projections ran where (the own GEMM takes a projection from _OWN_GEMM_MIN_TILES output tiles on), and how the sample-head
         # attention kernels split a sample's heads over workgroups (csrc/mha_sh.hip sh_heads_per_block: >= 256 workgroups when B allows)
         heads = {"tiny": 3}.get(args.model, 8)
         hpb = heads
         while hpb > 1 and args.batch * (heads // hpb) < 256:
             hpb = max(d for d in range(1, hpb) if heads % d == 0)
-        out["dispatch"] = {"launches_per_step": calls_per_step, "own_gemm_min_tiles": ops._OWN_GEMM_MIN_TILES,
+        out["dispatch"] = {"launches_per_step": calls_per_step,
+                           "own_gemm_min_tiles": "%d (%d where N >= 512)" % (ops._OWN_GEMM_MIN_TILES, ops._OWN_GEMM_MIN_TILES // 2),
                            "attention_heads_per_workgroup": hpb, "attention_workgroups": args.batch * (heads // hpb)}
         out.update(dpdiag)
         out.update(leg_out)

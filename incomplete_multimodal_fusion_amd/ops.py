@@ -203,9 +203,12 @@ OWN_GEMM = 1          # bit 0: forward / input-gradient projections of supported
                       # bound by the latency of its operand stream: 1546 TFLOP/s with every DMA hitting L2, 1040 from HBM at a 75 % L2 hit
                       # rate, no change from 3 to 5 staging steps in flight), +4.7 ms in the step -> OFF by default.
                       # 0: library GEMMs everywhere (tools/tuning_env.py: MMAE_OWN_GEMM)
-_OWN_GEMM_MIN_TILES = 256     # from one 256 x 256 output tile per CU on; below that the library's smaller tiles fill the chip better.  (512 until round 6:
-                              # at the reference's per-GPU batch, B = 64, that sent every N = 768 / 512 projection of the 40 960 rows to the library --
-                              # same-box A/B at B = 64: 44.94 / 45.01 ms per step at 512, 44.80 / 44.90 at 256, 44.85 / 44.72 at 128; B = 256 is not affected)
+_OWN_GEMM_MIN_TILES = 512     # from two 256 x 256 output tiles per CU on; below that the library's smaller tiles fill the chip better ...
+                              # ... except where the output is at least two tiles WIDE (N >= 512): from HALF of it (one tile per CU) on.  Round 6, same-box A/Bs: at the
+                              # reference's per-GPU batch (B = 64: 40 960 rows) a plain 512 sent every N = 768 / 512 projection to the library (44.94 / 45.01 ms
+                              # per step against 44.80 / 44.90 with them on the own kernel); a plain 256 also took the one-tile-wide N = 256 projections of
+                              # the 65 536 fusion rows at B = 256, ONE tile per persistent workgroup with nothing to overlap its prologue and epilogue with
+                              # (150.27 -> 150.63 ms per step, three alternations)
 CALLS = {"mmae_gemm_nt": 0, "mmae_gemm_geglu": 0, "mmae_gemm_tn": 0,      # launches of the own GEMM entry points (tests assert engagement)
          "library_matmul_nt": 0}                                          # ... and the projections matmul_nt handed to the library instead
 
@@ -244,7 +247,8 @@ def own_gemm_ok(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
         if out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1 or out.data_ptr() % 8:
             return False
         ldc = out.stride(0)
-    if ((M + 255) // 256) * (N // 256) < _OWN_GEMM_MIN_TILES:
+    tiles = ((M + 255) // 256) * (N // 256)
+    if tiles < _OWN_GEMM_MIN_TILES and not (N >= 512 and tiles >= _OWN_GEMM_MIN_TILES // 2):
         return False
     ok = bool(_lib.lib().mmae_gemm_nt_supported(M, N, K, x.stride(0), w.stride(0), ldc))
     if not ok and N % 256 == 0 and K % 128 == 0 and K >= 384:

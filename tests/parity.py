@@ -185,7 +185,7 @@ def chunked_oracle(state, x, masks, N, heads, dec_heads, chunk=8, bf16=False, do
 
 class own_gemm_engaged:
     """`with parity.own_gemm_engaged(): ...` -- the composition bench.py runs, at test sizes: every projection whose SHAPE the own
-    GEMM supports goes to it (ops._OWN_GEMM_MIN_TILES = 0; the product threshold of 256 tiles keeps B <= 8 steps on the library GEMM),
+    GEMM supports goes to it (ops._OWN_GEMM_MIN_TILES = 0; the product threshold of 512 (256 for N >= 512) output tiles keeps B <= 8 steps on the library GEMM),
     and on exit the context asserts that mmae_gemm_nt (and, when `geglu`, mmae_gemm_geglu) were actually launched.  min_tiles=None
     keeps the product threshold (the B = 64 step at default dispatch)."""
 

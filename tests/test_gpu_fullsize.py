@@ -66,7 +66,7 @@ def test_vitb_full_step_vs_oracle(mode):
 
 def test_vitb_batch64_bf16_step_at_product_dispatch_vs_oracle():
     """B = 64 (batch-shared masks, the headline bench's mask mode), bf16, the step through engine.FlatAdamW at the PRODUCT's own-GEMM
-    threshold (ops._OWN_GEMM_MIN_TILES untouched, 256 output tiles since round 6: at 40 960 rows every projection of the modality rows
+    threshold (ops._OWN_GEMM_MIN_TILES untouched; since round 6 from 256 output tiles on where N >= 512: at 40 960 rows every projection of the modality rows
     with N >= 512 runs on gemm8p_kernel, the fusion rows' narrow ones and the decoders on the library): every output, loss and parameter gradient against the oracle evaluated in
     chunks of 8 samples (tests/parity.chunked_oracle -- exact: every loss term is a mean over samples), anchored on the oracle's
     own bf16 arithmetic (the same chunked evaluation under CPU bf16 autocast)."""
