@@ -251,13 +251,9 @@ def mfma_busy():
         return None
 
 
-def mfma_busy_live(args, timeout_s=170):
-    """MFMA-busy % of THIS command measured on THIS box (the replayed figure comes from a committed profile): a child
-    `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 2 --legs none` run BEFORE this process
-    touches the GPU (a counter pass in its own process, sequential: nothing shares the card with the timed region), condensed exactly as
-    tools/prof_summary.py's `sq` does: sum of busy cycles / (1024 SIMDs x sum of GRBM_GUI_ACTIVE / 8 XCDs) over every dispatch.  Returns
-    None when rocprofv3 is not on this machine; an {"error": ...} object -- never an exception -- when the pass fails or times out."""
-    import collections
+def _counter_pass(args, counters, timeout_s):
+    """One child `rocprofv3 --pmc <counters> -- python3 bench.py --steps 2 --warmup 2 --legs none` of this command (its own process, run BEFORE
+    this process touches the GPU): -> (rows of counter_collection.csv, seconds).  Raises on failure."""
     import csv
     import glob
     import shutil
@@ -265,42 +261,79 @@ def mfma_busy_live(args, timeout_s=170):
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
-        return None
+        raise FileNotFoundError("rocprofv3")
     out_dir = tempfile.mkdtemp(prefix="mmae_pmc_", dir="/tmp")
-    steps = 2
-    cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", out_dir, "--",
-           sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--legs", "none",
+    cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "--",
+           sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--legs", "none",
            "--block-timer", "0", "--batch", str(args.batch)]
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
         if r.returncode != 0:
-            return {"error": "rocprofv3 pass exited with %d: %s" % (r.returncode, (r.stderr or "")[-200:])}
+            raise RuntimeError("rocprofv3 pass exited with %d: %s" % (r.returncode, (r.stderr or "")[-200:]))
         files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
         if not files:
-            return {"error": "rocprofv3 pass wrote no counter_collection.csv"}
-        tot = collections.defaultdict(float)
-        gemm = collections.defaultdict(float)
-        seen, ns = set(), 0
-        for x in csv.DictReader(open(files[0])):
-            tot[x["Counter_Name"]] += float(x["Counter_Value"])
-            if "gemm8p_kernel<0>" in x["Kernel_Name"]:
-                gemm[x["Counter_Name"]] += float(x["Counter_Value"])
-            if x["Dispatch_Id"] not in seen:
-                seen.add(x["Dispatch_Id"])
-                ns += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
-        simds = 1024.0 / 8.0
-        pct = lambda c: round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * c["GRBM_GUI_ACTIVE"]), 2) if c.get("GRBM_GUI_ACTIVE") else None
-        return {"pct": pct(tot), "gemm8p_kernel<0>_pct": pct(gemm), "kernel_ms_per_profiled_step": round(ns / 1e6 / (steps + 2), 2),
-                "pass_s": round(time.perf_counter() - t0, 1),
-                "source": "live: child `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 2 --legs none` "
-                          "on this box, before the timed region (all 4 steps of the pass counted)"}
-    except subprocess.TimeoutExpired:
-        return {"error": "rocprofv3 pass did not finish in %d s" % timeout_s}
-    except Exception as e:                                  # never lose the headline line over this leg
-        return {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
+            raise RuntimeError("rocprofv3 pass wrote no counter_collection.csv")
+        return list(csv.DictReader(open(files[0]))), time.perf_counter() - t0
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+PROFILED_STEPS = 4          # a counter pass runs 2 warm-up + 2 timed steps; every dispatch of it is counted
+
+
+def mfma_busy_live(args, timeout_s=120):
+    """MFMA-busy % and HBM traffic of THIS command measured on THIS box (the replayed figures come from a committed
+    profile): three child counter passes of `python3 bench.py --steps 2 --warmup 2 --legs none` under rocprofv3 -- SQ_VALU_MFMA_BUSY_CYCLES +
+    GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes) -- BEFORE this process touches the GPU
+    (sequential: nothing shares the card with the timed region), condensed exactly as tools/prof_summary.py does: busy = sum of busy cycles /
+    (1024 SIMDs x sum of GRBM_GUI_ACTIVE / 8 XCDs) over every dispatch; HBM bytes per launch = 2 x FETCH_SIZE KiB (the gfx950 half-count
+    rule) + WRITE_SIZE KiB, averaged over a kernel's launches.  Returns None when rocprofv3 is not on this machine; an {"error": ...} object --
+    never an exception -- when the first pass fails or times out (a failed traffic pass only leaves `traffic` to the replayed figures)."""
+    import collections
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.isfile("/opt/rocm/bin/rocprofv3")):
+        return None
+    try:
+        rows, secs = _counter_pass(args, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], timeout_s)
+    except Exception as e:                                  # never lose the headline line over this leg
+        return {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
+    tot, gemm = collections.defaultdict(float), collections.defaultdict(float)
+    seen, ns = set(), 0
+    for x in rows:
+        tot[x["Counter_Name"]] += float(x["Counter_Value"])
+        if "gemm8p_kernel<0>" in x["Kernel_Name"]:
+            gemm[x["Counter_Name"]] += float(x["Counter_Value"])
+        if x["Dispatch_Id"] not in seen:
+            seen.add(x["Dispatch_Id"])
+            ns += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+    simds = 1024.0 / 8.0
+    pct = lambda c: round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * c["GRBM_GUI_ACTIVE"]), 2) if c.get("GRBM_GUI_ACTIVE") else None
+    out = {"pct": pct(tot), "gemm8p_kernel<0>_pct": pct(gemm), "kernel_ms_per_profiled_step": round(ns / 1e6 / PROFILED_STEPS, 2), "pass_s": round(secs, 1),
+           "source": "live: child `rocprofv3 --pmc ... -- python3 bench.py --steps 2 --warmup 2 --legs none` passes on this box, before the timed "
+                     "region (all 4 steps of a pass counted)"}
+    try:                                                    # HBM traffic per launch of the three roofline kernels
+        per = {}
+        for counter, scale in (("FETCH_SIZE", 2 * 1024.0), ("WRITE_SIZE", 1024.0)):
+            rws, s2 = _counter_pass(args, [counter], timeout_s)
+            out["pass_s"] = round(out["pass_s"] + s2, 1)
+            acc = collections.defaultdict(list)
+            for x in rws:
+                if x["Counter_Name"] == counter:
+                    acc[x["Kernel_Name"]].append(float(x["Counter_Value"]))
+            for k, v in acc.items():
+                e = per.setdefault(k, {"bytes": 0.0, "launches": 0})
+                e["bytes"] += scale * sum(v) / len(v)
+                e["launches"] = max(e["launches"], len(v))
+        traffic = {}
+        for key in ("gemm8p_kernel<0>", "add_ln_bwd_fast_kernel", "mha_sh_fwd"):
+            cand = [v for name, v in per.items() if key in name]
+            if cand:                                        # several template instances: the one that moves the most bytes in the step
+                traffic[key] = round(max(cand, key=lambda c: c["launches"] * c["bytes"])["bytes"])
+        out["traffic_bytes_per_launch"] = traffic
+    except Exception as e:
+        out["traffic_error"] = ("%s: %s" % (type(e).__name__, e))[:200]
+    return out
 
 
 def event_bracket_overhead_ms(device, n=96):
@@ -674,6 +707,7 @@ def main():
         replay_ok = not args.fp32 and args.batch == 256 and default_doms and not (args.per_sample or args.dropout or args.staging)
         rep_sq, sq_ok = replayed_from("sq_step", ms) if replay_ok else (None, False)
         rep_hbm, hbm_ok = replayed_from("pmc_hbm", ms) if replay_ok else (None, False)
+        live_traffic = (live_busy or {}).get("traffic_bytes_per_launch") or {}        # measured on this box by mfma_busy_live's FETCH / WRITE passes
         out = {
             "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -693,7 +727,7 @@ def main():
             "roofline_hbm": {"kernel": "add_ln_bwd_fast_kernel<bf16,bf16,3,double,up,gx,gdelta>" if not args.fp32 else "add_ln_bwd_fast_kernel<f32,...>",
                          "bound": "hbm", "achieved": round(ln_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ln_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("add_ln_bwd_fast_kernel") if (replay_ok and hbm_ok) else None,
+                         "traffic": live_traffic.get("add_ln_bwd_fast_kernel") or (pmc_traffic("add_ln_bwd_fast_kernel") if (replay_ok and hbm_ok) else None),
                          "algorithmic_bytes_per_launch": round(ln_bytes / ln_n) if ln_n else 0,
                          "avg_launch_ms": round(ln_ms, 4), "avg_bracket_ms": round(ln_raw_ms, 4),
                          "event_bracket_overhead_ms": round(ev_ms, 4), "launches": ln_n,
@@ -702,7 +736,7 @@ def main():
             "roofline_attention": {"kernel": "+".join(sorted(prof.kernels)) or None,   # as routed by the library (mmae_mha_fwd_route)
                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
-                         "traffic": pmc_traffic("mha_sh_fwd") if (replay_ok and hbm_ok) else None,
+                         "traffic": live_traffic.get("mha_sh_fwd") or (pmc_traffic("mha_sh_fwd") if (replay_ok and hbm_ok) else None),
                          "algorithmic_flops_per_launch": round(flops / n_launch) if n_launch else 0,
                          "algorithmic_bytes_per_launch": args.batch * (args.num_encoded_tokens + (args.input_size // 16) ** 2) * 4 * 64 * {"tiny": 3}.get(args.model, 8) * 2,
                          "avg_launch_ms": round(avg_ms, 4), "avg_bracket_ms": round(raw_ms, 4),
@@ -746,7 +780,7 @@ def main():
             out["roofline"] = {"kernel": "gemm8p_kernel<0> (own persistent 256x256x64 8-phase bf16 GEMM: forward + input-gradient projections)",
                                "bound": "mfma", "achieved": round(g_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                "frac": round(g_tf / MFMA_BF16_PEAK_TF, 4),
-                               "traffic": pmc_traffic("gemm8p_kernel<0>") if (replay_ok and hbm_ok) else None,
+                               "traffic": live_traffic.get("gemm8p_kernel<0>") or (pmc_traffic("gemm8p_kernel<0>") if (replay_ok and hbm_ok) else None),
                                "algorithmic_flops_per_launch": round(g_fl / g_n), "avg_launch_ms": round(g_ms, 4),
                                "avg_bracket_ms": round(g_raw, 4), "event_bracket_overhead_ms": round(ev_ms, 4),
                                "launches": g_n, "launches_per_step": round(prof_gemm.seen / max(args.steps, 1), 1),
@@ -770,6 +804,8 @@ def main():
                 out["mfma_busy_pct_replayed"] = out.get("mfma_busy_pct")
                 out["mfma_busy_pct"] = live_busy["pct"]
                 out["mfma_busy_source"] = "live (mfma_busy_live)"
+            if live_traffic:
+                out["traffic_source"] = "live (mfma_busy_live: FETCH_SIZE / WRITE_SIZE passes of this command on this box)"
         # which projections ran where (the own GEMM takes a projection from _OWN_GEMM_MIN_TILES output tiles on), and how the sample-head
         # attention kernels split a sample's heads over workgroups (csrc/mha_sh.hip sh_heads_per_block: >= 256 workgroups when B allows)
         heads = {"tiny": 3}.get(args.model, 8)
