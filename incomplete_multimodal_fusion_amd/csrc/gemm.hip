@@ -108,13 +108,16 @@ struct GemmArgs {
     int ntm, ntn;                                        // tiles: ceil(M / 256) x N / 256 (EPI 1: F / 128)
 };
 
+#ifndef GM_GN
+#define GM_GN 8                   // N-tiles of a chunk: the W panels an XCD keeps L2-resident while its A panels stream (A/B knob)
+#endif
 struct TileXY { int tm, tn; };
 // Tiles of one XCD group x (= workgroup % 8: the workgroups that share an L2 under round-robin placement -- speed only): M-panels
 // [m0, m1), walked in chunks of up to 8 N-tiles (a chunk's W panels stay L2-resident while the A panels stream); local tile index i.
 __device__ __forceinline__ TileXY tile_of(int x, int i, int ntm, int ntn) {
     const int q = ntm / 8, r = ntm % 8;
     const int m0 = x * q + (x < r ? x : r), rows = q + (x < r ? 1 : 0);
-    const int GN = ntn < 8 ? ntn : 8, nc = ntn / GN, rem = ntn - nc * GN, full = nc * rows * GN;
+    const int GN = ntn < GM_GN ? ntn : GM_GN, nc = ntn / GN, rem = ntn - nc * GN, full = nc * rows * GN;
     TileXY t;
     if (i < full) { const int c = i / (rows * GN), rr = i - c * rows * GN; t.tm = m0 + rr / GN; t.tn = c * GN + rr % GN; }
     else { const int rr = i - full; t.tm = m0 + rr / rem; t.tn = nc * GN + rr % rem; }
