@@ -37,9 +37,10 @@ def main():
     print("\nPer-sample rate at B = 64: **%.0f %%** of the B = 256 rate (VERDICT r5 item 6: at or below 85 %% calls for the A/B of `_OWN_GEMM_MIN_TILES`; threshold of this line: %s output tiles)." % (
         100 * r, d64.get("own_gemm_min_tiles", "512")))
     if "value" in g:
-        print("Captured into one hipGraph (no host enqueue time at all) the B = 64 step still runs at only %.0f %% of the B = 256 rate: what separates the two "
-              "is the kernels at a quarter of the rows -- fewer tiles per persistent workgroup in the own GEMM (`roofline.frac`), shorter streaming launches "
-              "(`roofline_hbm.frac`) -- not the host." % (100 * g["value"] / b256["value"]))
+        print("Captured into one hipGraph (no host enqueue time at all) the B = 64 step runs at %.0f %% of the B = 256 rate (eager: %.0f %%; the host needs %.1f ms "
+              "to enqueue a step that takes %.1f ms -- on a box with a slower host the eager step is host-bound, and `PretrainStep.capture` is the remedy).  What "
+              "separates the captured step from the B = 256 rate is the kernels at a quarter of the rows: fewer tiles per persistent workgroup in the own GEMM "
+              "(`roofline.frac`), shorter streaming launches (`roofline_hbm.frac`)." % (100 * g["value"] / b256["value"], 100 * r, b64["host_enqueue_ms_per_step"], b64["ms_per_step"]))
 
 
 if __name__ == "__main__":

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
     VMCNT(0);
 }
 
+#ifndef PROBE_NO_MAIN
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 163840, N = argc > 2 ? atoi(argv[2]) : 4096;
     constexpr int K = 768;
@@ -316,3 +317,4 @@ int main(int argc, char** argv) {
            M, N, K, diag, tot / rounds * 1e3, fl / (tot / rounds * 1e-3) / 1e12, best * 1e3, fl / (best * 1e-3) / 1e12, checked, bad, worst);
     return bad ? 2 : 0;
 }
+#endif

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_persist_kernel(const bf16* __re
     STAGGER(wr == 0);
 }
 
+#ifndef PROBE_NO_MAIN
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 163840, N = argc > 2 ? atoi(argv[2]) : 4096;
     constexpr int K = 768;
@@ -552,3 +553,4 @@ int main(int argc, char** argv) {
     if (diag) printf("  (diag %d: timing experiment, the timed launches compute wrong results by construction)\n", diag);
     return bad ? 2 : 0;
 }
+#endif
