@@ -37,7 +37,7 @@ KEEP = [{"s1": 9, "s2": 7, "dem": 0}, {"s1": 6, "s2": 5, "dem": 5}, {"s1": 4, "s
         {"s1": 7, "s2": 2, "dem": 7}]                                          # 16 kept tokens per step, a dropped modality in two of them
 
 
-def _oracle_trajectory(state, x, masks, bf16, keep_grads=False):
+def _oracle_trajectory(state, x, masks, bf16, keep_grads=False, heads=HEADS, N=16):
     p = parity.leaf_params(state)
     train = [t for t in p.values() if t.requires_grad]
     opt = torch.optim.AdamW(train, lr=LR, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8)
@@ -45,7 +45,7 @@ def _oracle_trajectory(state, x, masks, bf16, keep_grads=False):
     grads = []
     for m in masks:
         opt.zero_grad(set_to_none=True)                                        # a parameter without a gradient is skipped, as in the engine
-        _, (tl, lc, loss) = O.train_step_loss(p, x, m, 16, HEADS, 8, 16, bf16=bf16)
+        _, (tl, lc, loss) = O.train_step_loss(p, x, m, N, heads, 8, 16, bf16=bf16)
         loss.backward()
         for k, v in p.items():
             if v.requires_grad and v.grad is not None:
@@ -57,14 +57,14 @@ def _oracle_trajectory(state, x, masks, bf16, keep_grads=False):
     return losses, {k: v.detach().double() for k, v in p.items()}, (grads if keep_grads else gmax)
 
 
-def _native_trajectory(base_state, x, masks, autocast):
+def _native_trajectory(base_state, x, masks, autocast, model=None, N=16):
     from incomplete_multimodal_fusion_amd.engine import FlatAdamW
     from incomplete_multimodal_fusion_amd.pretrain import PretrainStep
-    model = _model("tiny", SIZE, 31)
+    model = _model("tiny", SIZE, 31) if model is None else model
     model.load_state_dict(base_state)
     model.to(DEV).train()
     opt = FlatAdamW(model.parameters(), lr=LR, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, exclude=model.never_used_parameters())
-    step = PretrainStep(model, opt, 16, autocast=autocast)
+    step = PretrainStep(model, opt, N, autocast=autocast)
     xd = {k: v.to(DEV) for k, v in x.items()}
     losses = []
     for m in masks:
@@ -149,5 +149,34 @@ def test_training_trajectory_vs_oracle_bf16_anchored():
     d_anc = float((cat(anc_w) - dref).norm() / dref.norm())
     print("\n[trajectory bf16] %d steps: worst loss err %.2e (reference-bf16 %.2e); update rel L2 %.3e vs reference-bf16 %.3e (ratio %.2f)"
           % (STEPS, e, ea, d_hip, d_anc, d_hip / max(d_anc, 1e-30)))
+    assert e <= max(1e-2, 1.5 * ea), (e, ea)
+    assert d_hip <= max(1e-2, 1.5 * d_anc), (d_hip, d_anc)
+
+
+def test_training_trajectory_vitb_bench_composition_bf16_anchored():
+    """The bench's own composition over steps: ViT-B (D768 / L12 / 8 heads), 256 x 256 tiles, B = 2, bf16, THREE steps with every supported
+    projection on the own GEMM (tests/parity.own_gemm_engaged: forward and input-gradient GEMMs through the engine's bf16 shadow and its
+    TRANSPOSED shadow, FF1 + GEGLU epilogue) and the flat AdamW engine refreshing those shadows after every update -- what a one-step test
+    cannot see is a shadow (plain, transposed, padded) that is stale in step 2.  Against the oracle + torch.optim.AdamW in fp32, anchored on
+    the oracle's own bf16 trajectory exactly as the tiny-model case above."""
+    from tests.test_gpu_fullsize import CHANNELS, VITB, _vitb
+    base = _vitb(27)
+    state = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    torch.manual_seed(78)
+    x = {d: torch.randn(2, c, 256, 256) for d, c in CHANNELS}
+    masks = [_masks(256, 2, k) for k in ({"s1": 170, "s2": 41, "dem": 173}, {"s1": 128, "s2": 128, "dem": 128}, {"s1": 0, "s2": 200, "dem": 184})]
+    ref_losses, ref_w, _ = _oracle_trajectory(state, x, masks, bf16=False, heads=VITB["heads"], N=384)
+    anc_losses, anc_w, _ = _oracle_trajectory(state, x, masks, bf16=True, heads=VITB["heads"], N=384)
+    with parity.own_gemm_engaged():
+        got_losses, got_w = _native_trajectory(state, x, masks, autocast=True, model=base, N=384)
+    e, ea = _loss_errs(got_losses, ref_losses), _loss_errs(anc_losses, ref_losses)
+    keys = [k for k, r in ref_w.items() if r.dtype.is_floating_point and float((r - state[k].double()).abs().max()) > 0]
+    cat = lambda w: torch.cat([(w[k] - state[k].double()).flatten() for k in keys])
+    dref = cat(ref_w)
+    d_hip = float((cat(got_w) - dref).norm() / dref.norm())
+    d_anc = float((cat(anc_w) - dref).norm() / dref.norm())
+    print("\n[trajectory ViT-B bf16, own GEMM + engine] 3 steps: worst loss err %.2e (reference-bf16 %.2e); update rel L2 %.3e vs reference-bf16 %.3e "
+          "(ratio %.2f)" % (e, ea, d_hip, d_anc, d_hip / max(d_anc, 1e-30)))
+    assert len(keys) == 323
     assert e <= max(1e-2, 1.5 * ea), (e, ea)
     assert d_hip <= max(1e-2, 1.5 * d_anc), (d_hip, d_anc)
