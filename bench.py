@@ -268,9 +268,22 @@ def _counter_pass(args, counters, timeout_s):
            "--block-timer", "0", "--batch", str(args.batch)]
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
-        if r.returncode != 0:
-            raise RuntimeError("rocprofv3 pass exited with %d: %s" % (r.returncode, (r.stderr or "")[-200:]))
+        # its own process group: on a timeout the profiler AND the bench process under it are killed (an orphaned pass would share the card
+        # with the timed region)
+        proc = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                start_new_session=True)
+        try:
+            _, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
+            raise RuntimeError("rocprofv3 pass did not finish in %d s (killed)" % timeout_s)
+        if proc.returncode != 0:
+            raise RuntimeError("rocprofv3 pass exited with %d: %s" % (proc.returncode, (err or "")[-200:]))
         files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             raise RuntimeError("rocprofv3 pass wrote no counter_collection.csv")
