@@ -563,7 +563,8 @@ def main():
     # the live MFMA-busy pass: only for the default invocation at N = 1 (`--legs auto`), and before anything here touches the GPU
     headline_cfg = args.domains == "s1,s2,dem" and args.fusion_blocks and args.contra == "dino" and args.model == "base" and \
         not (args.staging or args.per_sample or args.dropout or args.fp32) and args.batch == 256
-    live_busy = mfma_busy_live(args) if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)   # (never nest profilers)
+    live_busy = mfma_busy_live(args) if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not profiled and
                                          (args.legs == "auto" and headline_cfg or "mfma" in args.legs.split(","))) else None
     if args.tuning_env:
         from tools import tuning_env
